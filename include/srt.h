@@ -1,0 +1,165 @@
+/* include/srt.h -- C ABI of the MI355X-native ray-trace core for simple_raytracer scenes.
+ *
+ * This is the drop-in boundary for ONE path of leonlang/simple_raytracer: the per-pixel loop
+ *
+ *     ImageData sendRaysAndIntersectPointsColors(const glm::vec2& imageSize,
+ *                                                const glm::vec4& lightPos,
+ *                                                ObjectManager* objManager);   // simple_raytracer.cpp:505
+ *
+ * called once per frame from main() (simple_raytracer.cpp:784) and consumed by drawImage (:793).
+ * The reference has no FFI of its own; the seam is that one call.  Everything here is plain C:
+ * PODs, caller-owned buffers, int return codes, no exceptions, no glm / STL / torch types.
+ * All compute behind these entry points is hand-written HIP for gfx950; there is NO CPU fallback
+ * (the CPU restatement used to check results lives in oracle/ and is test infrastructure only).
+ *
+ * Thread-safety: one host thread per srt_scene handle.  One handle lives on one HIP device.
+ */
+#ifndef SRT_H
+#define SRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_ABI_VERSION 1
+
+/* ---- error codes (the reference signals nothing: it prints, throws or crashes) -- */
+enum {
+    SRT_OK              = 0,
+    SRT_ERR_ARG         = 1,   /* null pointer / zero size / inconsistent counts                    */
+    SRT_ERR_LAYOUT      = 2,   /* scene arrays violate the layout contract below                    */
+    SRT_ERR_DEVICE      = 3,   /* HIP runtime error (srt_last_hip_error() has the hipError_t)       */
+    SRT_ERR_NO_GPU      = 4,   /* no HIP device visible: the product path never falls back to CPU   */
+    SRT_ERR_TEXTURE     = 5,   /* triangle references a texture id >= n_textures                    */
+    SRT_ERR_LIMIT       = 6    /* size exceeds an implementation limit (n_tris < 2^27, ...)          */
+};
+
+/* ---- flat scene: what the host hands over once per frame ---------------------------------------
+ * It is the reference's ObjectManager state (Object.h:59-89) with the string-keyed maps and Node*
+ * trees written out as arrays:
+ *   objects    in objTriangles iteration order (the order rayIntersection:409 visits them),
+ *   nodes      each object's Node tree (Object.h:46-57) in any order, children by global index,
+ *   triangles  in VISIT order: object order -> DFS left-first leaf order (boundingBoxIntersection
+ *              :296-317) -> in-leaf order.  The index in this order is the canonical triangle id
+ *              reported in hit_id, and ties in t resolve to the lowest id exactly as the reference's
+ *              strict '<' (:429) does.
+ * Layout contract (checked, SRT_ERR_LAYOUT): every node is reachable from exactly one root; a leaf
+ * has left == right == -1 and owns triangles [first, first+count), 0 <= count; walking all objects'
+ * trees DFS left-first meets the leaves' ranges contiguously in increasing order, covering
+ * [0, n_tris) exactly once; tri_obj[i] equals the object whose tree owns triangle i.
+ */
+typedef struct srt_scene_desc {
+    uint32_t n_objects, n_nodes, n_tris, n_textures;
+    /* nodes: Node::minBox / maxBox (Object.h:47-48), left / right (:50-51) */
+    const float*    node_min;      /* n_nodes x 3                                                   */
+    const float*    node_max;      /* n_nodes x 3                                                   */
+    const int32_t*  node_left;     /* n_nodes, global child index or -1                             */
+    const int32_t*  node_right;    /* n_nodes                                                       */
+    const int32_t*  node_first;    /* n_nodes, first triangle of a leaf (ignored for inner nodes)   */
+    const int32_t*  node_count;    /* n_nodes, triangle count of a leaf (ignored for inner nodes)   */
+    const uint32_t* obj_root;      /* n_objects, root node of each object's tree                    */
+    /* triangles: Triangle::pointOne/Two/Three (Object.h:17-19) as raw homogeneous xyzw             */
+    const float*    tri_points;    /* n_tris x 3 x 4                                                */
+    const int32_t*  tri_obj;       /* n_tris, owning object                                         */
+    const int32_t*  tri_tex;       /* n_tris, texture id or -1 (Triangle::textureName empty)        */
+    const float*    tri_texcoord;  /* n_tris x 6, colorOne/Two/ThreeCoordinate (Object.h:23-25):    */
+                                   /* integer texel coords stored as floats; may be NULL if no tex  */
+    const float*    tri_normals;   /* n_tris x 9 vertex normals (Object.h:20-22) or NULL; only read */
+                                   /* with SRT_FLAG_SMOOTH_NORMALS                                   */
+    /* objects: objColors / objProperties (Object.h:64,68) */
+    const float*    obj_color;     /* n_objects x 3                                                 */
+    const float*    obj_material;  /* n_objects x 3: ambient, specularStrength, shininess           */
+    /* textures: textureData / textureDimensions (Object.h:70-71), 8-bit RGB rows top-down          */
+    const uint8_t*  tex_rgb;       /* concatenated                                                  */
+    const uint64_t* tex_off;       /* n_textures byte offsets into tex_rgb                          */
+    const uint32_t* tex_w;         /* n_textures                                                    */
+    const uint32_t* tex_h;         /* n_textures                                                    */
+} srt_scene_desc;
+
+/* ---- render parameters: every compile-time literal of the reference path, as data -------------- */
+enum {
+    SRT_FLAG_NONE           = 0,
+    SRT_FLAG_SMOOTH_NORMALS = 1u << 0,  /* interpolateNormal (simple_raytracer.cpp:132-140,162)     */
+    SRT_FLAG_COUNT_WORK     = 1u << 1   /* run the counting build: fills node/tri test counters      */
+};
+
+typedef struct srt_params {
+    uint32_t width, height;        /* imageSize (simple_raytracer.cpp:773)                          */
+    /* scanline blocks rendered by THIS call: blocks of block_rows rows; this call owns blocks
+     * block_first, block_first+block_stride, ...  Output row r_local = k*block_rows + (y % block_rows)
+     * for the k-th owned block.  Whole frame on one device: block_rows = height, first 0, stride 1. */
+    uint32_t block_rows, block_first, block_stride;
+    float    focal;                /* 400 (:506)                                                    */
+    uint32_t n_lights;             /* lightAmount (:348,445)                                        */
+    const float* light_pos;        /* n_lights x 3, host-accumulated staircase (:372-382)           */
+    float    shadow_div;           /* 5   (:369)                                                    */
+    float    reinhard;             /* 0.5 (:391)                                                    */
+    float    gamma;                /* 1.1 (:396)                                                    */
+    uint8_t  background[4];        /* 173,216,230 (:476); [3] unused                                */
+    uint32_t spp;                  /* 1 = reference; >1 = extension, sqrt(spp) x sqrt(spp) grid      */
+    uint32_t flags;
+} srt_params;
+
+typedef struct srt_stats {
+    uint64_t primary_rays;         /* width x owned rows x spp                                      */
+    uint64_t hit_rays;             /* primary rays that hit                                         */
+    uint64_t shadow_rays;          /* hit_rays x n_lights (algorithmic count)         */
+    uint64_t node_tests;           /* slab tests executed (SRT_FLAG_COUNT_WORK only, else 0)        */
+    uint64_t tri_tests;            /* Moller-Trumbore tests executed (idem)                         */
+    float    ms_primary;           /* HIP-event time of the closest-hit kernel                      */
+    float    ms_shade;             /* HIP-event time of the shadow + shading kernel                 */
+    float    ms_total;             /* first launch -> last kernel done                              */
+    uint32_t rows;                 /* rows written by this call                                     */
+} srt_stats;
+
+typedef struct srt_scene srt_scene;     /* opaque: device-resident flat scene + workspace           */
+
+/* Fill p with the reference's literals for a WxH frame and one light at (lx,ly,lz) rendered
+ * whole on one device.  light_pos is left NULL: point it at a table (srt_light_staircase). */
+void srt_params_default(srt_params* p, uint32_t width, uint32_t height);
+
+/* The soft-shadow light table of softShadow (simple_raytracer.cpp:363-383): sample 0 = base, then
+ * x, y, z, x, ... += 3.0f accumulated in f32 exactly as the reference does.  out = n x 3. */
+void srt_light_staircase(const float base[3], uint32_t n, float* out);
+
+/* Number of rows a call with these params writes (<= height). */
+uint32_t srt_rows_owned(const srt_params* p);
+
+/* Validate + upload a flat scene to HIP device `device`.  The descriptor's arrays are only read
+ * during the call. */
+int srt_scene_create(int device, const srt_scene_desc* desc, srt_scene** out);
+int srt_scene_destroy(srt_scene* s);
+
+/* Render into DEVICE buffers (rows = srt_rows_owned(p)); any output pointer may be NULL.
+ *   d_hit_id     rows x W   int32   canonical triangle id, -1 = miss
+ *   d_t          rows x W   f32     closest-hit distance (+inf on miss)
+ *   d_rgb_linear rows x W x 3 f32   pre-tone-map light-sample sum (softShadow:362-383); 0 on miss
+ *   d_rgb8       rows x W x 3 u8    tone-mapped, quantised (:391-398,447-449), black -> background
+ *                                   (:518, drawImage:476-487)
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream); stats->ms_* are valid after
+ * srt_sync().  */
+int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
+                      int32_t* d_hit_id, float* d_t, float* d_rgb_linear, uint8_t* d_rgb8);
+
+/* Same, into HOST buffers: allocates nothing per call beyond the scene's workspace, copies back,
+ * synchronises.  stats may be NULL. */
+int srt_render(srt_scene* s, const srt_params* p,
+               int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, srt_stats* stats);
+
+/* Wait for the last srt_render_device on this scene and collect its stats. */
+int srt_sync(srt_scene* s, srt_stats* stats);
+
+/* Device-resident size of the scene records and the per-record algorithmic byte sizes used by
+ * the bytes model: 32 B per node test, 36 B per triangle test. */
+uint64_t srt_scene_device_bytes(const srt_scene* s);
+
+const char* srt_strerror(int code);
+int         srt_last_hip_error(void);
+uint32_t    srt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_H */

@@ -1,0 +1,342 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes loaders for the two checkers:
+  * liboracle.so          the plain-C restatement (oracle/srt_oracle.c)
+  * _ref/libsrt_ref.so    the reference's own sources behind oracle/ref_harness.cpp (optional)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from simple_raytracer_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p, _i32p, _u8p, _u32p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+
+
+def build(verbose=False):
+    """(Re)build the checkers with oracle/Makefile (gcc; g++ for the reference when present)."""
+    r = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout, r.stderr)
+    if r.returncode:
+        raise RuntimeError("oracle build failed")
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_render.restype = C.c_int
+        L.oracle_render.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Params), _i32p, _f32p, _f32p, _f32p, _u8p,
+                                    C.POINTER(abi.Stats), C.c_int]
+        L.oracle_rows_owned.restype = C.c_uint32
+        L.oracle_rows_owned.argtypes = [C.POINTER(abi.Params)]
+        L.oracle_num_threads.restype = C.c_int
+        _oracle = L
+    return _oracle
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+def render(scene: abi.FlatScene, params: abi.Params, n_threads=0):
+    """Run the C restatement.  Returns dict(hit_id, t, rgb_linear, rgb_tone, rgb8, stats)."""
+    L = oracle_lib()
+    rows = L.oracle_rows_owned(C.byref(params))
+    W = params.width
+    out = dict(hit_id=np.empty((rows, W), np.int32), t=np.empty((rows, W), np.float32),
+               rgb_linear=np.empty((rows, W, 3), np.float32), rgb_tone=np.empty((rows, W, 3), np.float32),
+               rgb8=np.empty((rows, W, 3), np.uint8))
+    st = abi.Stats()
+    d = scene.desc()
+    rc = L.oracle_render(C.byref(d), C.byref(params), _p(out["hit_id"], _i32p), _p(out["t"], _f32p),
+                         _p(out["rgb_linear"], _f32p), _p(out["rgb_tone"], _f32p), _p(out["rgb8"], _u8p), C.byref(st), n_threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed: {rc}")
+    out["stats"] = st.as_dict()
+    return out
+
+
+def ray_triangle(ray_od, tri):
+    L = oracle_lib()
+    ray_od = np.ascontiguousarray(ray_od, np.float32); tri = np.ascontiguousarray(tri, np.float32)
+    n = ray_od.shape[0]; t = np.empty(n, np.float32)
+    L.oracle_ray_triangle(C.c_uint32(n), _p(ray_od, _f32p), _p(tri, _f32p), _p(t, _f32p))
+    return t
+
+
+def ray_aabb(ray_od, box):
+    L = oracle_lib()
+    ray_od = np.ascontiguousarray(ray_od, np.float32); box = np.ascontiguousarray(box, np.float32)
+    n = ray_od.shape[0]; h = np.empty(n, np.uint8)
+    L.oracle_ray_aabb(C.c_uint32(n), _p(ray_od, _f32p), _p(box, _f32p), _p(h, _u8p))
+    return h
+
+
+def phong(inp):
+    L = oracle_lib()
+    inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; rgb = np.empty((n, 3), np.float32)
+    L.oracle_phong(C.c_uint32(n), _p(inp, _f32p), _p(rgb, _f32p))
+    return rgb
+
+
+def barycentric(inp):
+    L = oracle_lib()
+    inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; uvw = np.empty((n, 3), np.float32)
+    L.oracle_barycentric(C.c_uint32(n), _p(inp, _f32p), _p(uvw, _f32p))
+    return uvw
+
+
+def tonemap(lin, reinhard=0.5, gamma=1.1):
+    L = oracle_lib()
+    lin = np.ascontiguousarray(lin, np.float32).reshape(-1, 3); n = lin.shape[0]
+    tone = np.empty((n, 3), np.float32); q = np.empty((n, 3), np.int32)
+    L.oracle_tonemap(C.c_uint32(n), _p(lin, _f32p), C.c_float(reinhard), C.c_float(gamma), _p(tone, _f32p), _p(q, _i32p))
+    return tone, q
+
+
+def light_staircase(base, n):
+    L = oracle_lib()
+    b = (C.c_float * 3)(*[float(x) for x in base[:3]])
+    out = np.empty((n, 3), np.float32)
+    L.oracle_light_staircase(b, C.c_uint32(n), _p(out, _f32p))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The compiled reference (only where oracle/_ref/libsrt_ref.so exists)
+# ------------------------------------------------------------------------------------------------
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libsrt_ref.so"))
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libsrt_ref.so"))
+        L.ref_om_new.restype = C.c_void_p
+        L.ref_om_num_tris.restype = C.c_uint32
+        L.ref_om_object_order.restype = C.c_uint32
+        L.ref_om_tri_texture_name.restype = C.c_uint32
+        L.ref_om_texture.restype = C.c_int
+        L.ref_render.restype = C.c_uint32
+        L.ref_radians.restype = C.c_float
+        L.ref_radians.argtypes = [C.c_float]
+        for name in ("ref_mat_rotx", "ref_mat_roty", "ref_mat_rotz"):
+            getattr(L, name).argtypes = [C.c_float, _f32p]
+        L.ref_mat_scale.argtypes = [C.c_float] * 3 + [_f32p]
+        L.ref_mat_translate.argtypes = [C.c_float] * 3 + [_f32p]
+        L.ref_mat_shear.argtypes = [C.c_float] * 6 + [_f32p]
+        L.ref_mat_mirror.argtypes = [C.c_int] * 3 + [_f32p]
+        L.ref_om_set_color.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
+        L.ref_om_set_props.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
+        _ref = L
+    return _ref
+
+
+class RefMat:
+    """Transformation.h:10-20 factories + the glm ops main() applies, evaluated by the reference."""
+
+    @staticmethod
+    def _m(fn, *a):
+        out = np.empty(16, np.float32); fn(*a, _p(out, _f32p)); return out
+
+    @staticmethod
+    def radians(d): return float(ref_lib().ref_radians(C.c_float(d)))
+    @staticmethod
+    def scale(x, y, z): return RefMat._m(ref_lib().ref_mat_scale, x, y, z)
+    @staticmethod
+    def rotx(a): return RefMat._m(ref_lib().ref_mat_rotx, a)
+    @staticmethod
+    def roty(a): return RefMat._m(ref_lib().ref_mat_roty, a)
+    @staticmethod
+    def rotz(a): return RefMat._m(ref_lib().ref_mat_rotz, a)
+    @staticmethod
+    def mirror(x, y, z): return RefMat._m(ref_lib().ref_mat_mirror, int(x), int(y), int(z))
+    @staticmethod
+    def shear(*s): return RefMat._m(ref_lib().ref_mat_shear, *s)
+    @staticmethod
+    def translate(x, y, z): return RefMat._m(ref_lib().ref_mat_translate, x, y, z)
+
+    @staticmethod
+    def view(pos, rot):
+        pos = np.asarray(pos, np.float32); rot = np.asarray(rot, np.float32); out = np.empty(16, np.float32)
+        ref_lib().ref_mat_view(_p(pos, _f32p), _p(rot, _f32p), _p(out, _f32p)); return out
+
+    @staticmethod
+    def inverse(m):
+        m = np.ascontiguousarray(m, np.float32); out = np.empty(16, np.float32)
+        ref_lib().ref_mat_inverse(_p(m, _f32p), _p(out, _f32p)); return out
+
+    @staticmethod
+    def mul(a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); out = np.empty(16, np.float32)
+        ref_lib().ref_mat_mul(_p(a, _f32p), _p(b, _f32p), _p(out, _f32p)); return out
+
+    @staticmethod
+    def mul_vec4(a, v):
+        a = np.ascontiguousarray(a, np.float32); v = np.ascontiguousarray(v, np.float32); out = np.empty(4, np.float32)
+        ref_lib().ref_mat_mul_vec4(_p(a, _f32p), _p(v, _f32p), _p(out, _f32p)); return out
+
+
+class RefScene:
+    """The reference's ObjectManager driven through oracle/ref_harness.cpp."""
+
+    def __init__(self):
+        self.L = ref_lib()
+        self.om = C.c_void_p(self.L.ref_om_new())
+
+    def load_obj(self, name, cwd="/root/reference"):
+        old = os.getcwd()
+        os.chdir(cwd)          # asset and texture paths are cwd-relative in the reference
+        try:
+            self.L.ref_om_load_obj(self.om, name.encode())
+        finally:
+            os.chdir(old)
+
+    def add_object(self, name, points):
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 12)
+        self.L.ref_om_add_object(self.om, name.encode(), C.c_uint32(pts.shape[0]), _p(pts, _f32p))
+
+    def clone(self, src, dst): self.L.ref_om_clone(self.om, src.encode(), dst.encode())
+    def set_color(self, name, rgb): self.L.ref_om_set_color(self.om, name.encode(), *[float(x) for x in rgb])
+    def set_props(self, name, p): self.L.ref_om_set_props(self.om, name.encode(), *[float(x) for x in p])
+
+    def transform(self, name, m):
+        m = np.ascontiguousarray(m, np.float32)
+        self.L.ref_om_transform(self.om, name.encode(), _p(m, _f32p))
+
+    def build_bvh(self, name): self.L.ref_om_build_bvh(self.om, name.encode())
+
+    def points(self, name):
+        n = self.L.ref_om_num_tris(self.om, name.encode())
+        out = np.empty((n, 3, 4), np.float32)
+        self.L.ref_om_get_points(self.om, name.encode(), _p(out, _f32p))
+        return out
+
+    def tri_attrs(self, name):
+        n = self.L.ref_om_num_tris(self.om, name.encode())
+        tc = np.empty((n, 6), np.float32); col = np.empty((n, 3), np.float32); ht = np.empty(n, np.int32); nrm = np.empty((n, 9), np.float32)
+        self.L.ref_om_get_tri_attrs(self.om, name.encode(), _p(tc, _f32p), _p(col, _f32p), _p(ht, _i32p), _p(nrm, _f32p))
+        return tc, col, ht, nrm
+
+    def tri_texture_name(self, name, i):
+        buf = C.create_string_buffer(1024)
+        self.L.ref_om_tri_texture_name(self.om, name.encode(), C.c_uint32(i), buf, C.c_uint32(1024))
+        return buf.value.decode()
+
+    def texture(self, texname):
+        w, h = C.c_int32(), C.c_int32()
+        if not self.L.ref_om_texture(self.om, texname.encode(), C.byref(w), C.byref(h), None):
+            return None
+        rgb = np.empty((h.value, w.value, 3), np.uint8)
+        self.L.ref_om_texture(self.om, texname.encode(), C.byref(w), C.byref(h), _p(rgb, _u8p))
+        return rgb
+
+    def object_order(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.L.ref_om_object_order(self.om, buf, C.c_uint32(1 << 16))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    def export(self, textures=None) -> abi.FlatScene:
+        """Flat scene straight from the reference's Node* trees (also tags leaves for trace())."""
+        no, nn, nt = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.ref_om_counts(self.om, C.byref(no), C.byref(nn), C.byref(nt))
+        no, nn, nt = no.value, nn.value, nt.value
+        a = dict(obj_root=np.empty(no, np.uint32), obj_color=np.empty((no, 3), np.float32), obj_material=np.empty((no, 3), np.float32),
+                 node_min=np.empty((nn, 3), np.float32), node_max=np.empty((nn, 3), np.float32),
+                 node_left=np.empty(nn, np.int32), node_right=np.empty(nn, np.int32),
+                 node_first=np.empty(nn, np.int32), node_count=np.empty(nn, np.int32),
+                 tri_points=np.empty((nt, 3, 4), np.float32), tri_texcoord=np.empty((nt, 6), np.float32),
+                 tri_color=np.empty((nt, 3), np.float32), tri_obj=np.empty(nt, np.int32), tri_has_tex=np.empty(nt, np.int32))
+        self.L.ref_om_export(self.om, _p(a["obj_root"], _u32p), _p(a["obj_color"], _f32p), _p(a["obj_material"], _f32p),
+                             _p(a["node_min"], _f32p), _p(a["node_max"], _f32p), _p(a["node_left"], _i32p), _p(a["node_right"], _i32p),
+                             _p(a["node_first"], _i32p), _p(a["node_count"], _i32p),
+                             _p(a["tri_points"], _f32p), _p(a["tri_texcoord"], _f32p), _p(a["tri_color"], _f32p),
+                             _p(a["tri_obj"], _i32p), _p(a["tri_has_tex"], _i32p))
+        names = self.object_order()
+        tri_tex = np.full(nt, -1, np.int32)
+        tex_kw = {}
+        if a["tri_has_tex"].any():
+            # texture ids: per object, the textureName of each triangle, looked up in leaf order via
+            # the per-object loader arrays is not possible after the BVH sort, so resolve by name here.
+            assert textures is not None, "textured scene: pass textures={object name: texture name}"
+            tex_names, rgbs = [], []
+            for k, nm in enumerate(names):
+                tn = textures.get(nm)
+                if tn is None:
+                    continue
+                if tn not in tex_names:
+                    img = self.texture(tn)
+                    assert img is not None, f"texture {tn} not loaded by the reference"
+                    tex_names.append(tn); rgbs.append(img)
+                sel = (a["tri_obj"] == k) & (a["tri_has_tex"] != 0)
+                tri_tex[sel] = tex_names.index(tn)
+            offs = np.cumsum([0] + [r.size for r in rgbs[:-1]]).astype(np.uint64)
+            tex_kw = dict(tex_rgb=np.concatenate([r.reshape(-1) for r in rgbs]), tex_off=offs,
+                          tex_w=np.array([r.shape[1] for r in rgbs], np.uint32), tex_h=np.array([r.shape[0] for r in rgbs], np.uint32))
+        return abi.FlatScene(node_min=a["node_min"], node_max=a["node_max"], node_left=a["node_left"], node_right=a["node_right"],
+                             node_first=a["node_first"], node_count=a["node_count"], obj_root=a["obj_root"],
+                             tri_points=a["tri_points"], tri_obj=a["tri_obj"], obj_color=a["obj_color"], obj_material=a["obj_material"],
+                             tri_tex=tri_tex, tri_texcoord=a["tri_texcoord"], names=names, **tex_kw)
+
+    def render(self, W, H, light4):
+        """sendRaysAndIntersectPointsColors itself -> dense H x W x 3 float image (0 where nothing emitted)."""
+        light4 = np.ascontiguousarray(light4, np.float32)
+        rgb = np.empty((H, W, 3), np.float32)
+        n = self.L.ref_render(self.om, C.c_uint32(W), C.c_uint32(H), _p(light4, _f32p), _p(rgb, _f32p))
+        return rgb, n
+
+    def trace(self, W, H, light3, n_lights):
+        """Closest-hit ids / t / softShadow(n_lights) / pre-tone-map sums via the reference's leaf functions."""
+        light3 = np.ascontiguousarray(light3, np.float32)
+        hit = np.empty((H, W), np.int32); t = np.empty((H, W), np.float32)
+        tone = np.empty((H, W, 3), np.float32); lin = np.empty((H, W, 3), np.float32)
+        self.L.ref_trace(self.om, C.c_uint32(W), C.c_uint32(H), _p(light3, _f32p), C.c_int(n_lights),
+                         _p(hit, _i32p), _p(t, _f32p), _p(tone, _f32p), _p(lin, _f32p))
+        return hit, t, tone, lin
+
+
+def ref_kat_ray_triangle(ray_od, tri):
+    L = ref_lib(); ray_od = np.ascontiguousarray(ray_od, np.float32); tri = np.ascontiguousarray(tri, np.float32)
+    n = ray_od.shape[0]; t = np.empty(n, np.float32)
+    L.ref_kat_ray_triangle(C.c_uint32(n), _p(ray_od, _f32p), _p(tri, _f32p), _p(t, _f32p)); return t
+
+
+def ref_kat_ray_aabb(ray_od, box):
+    L = ref_lib(); ray_od = np.ascontiguousarray(ray_od, np.float32); box = np.ascontiguousarray(box, np.float32)
+    n = ray_od.shape[0]; h = np.empty(n, np.uint8); h0 = np.empty(n, np.uint8)
+    L.ref_kat_ray_aabb(C.c_uint32(n), _p(ray_od, _f32p), _p(box, _f32p), _p(h, _u8p), _p(h0, _u8p)); return h, h0
+
+
+def ref_kat_phong(inp):
+    L = ref_lib(); inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; rgb = np.empty((n, 3), np.float32)
+    L.ref_kat_phong(C.c_uint32(n), _p(inp, _f32p), _p(rgb, _f32p)); return rgb
+
+
+def ref_kat_barycentric(inp):
+    L = ref_lib(); inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; uvw = np.empty((n, 3), np.float32)
+    L.ref_kat_barycentric(C.c_uint32(n), _p(inp, _f32p), _p(uvw, _f32p)); return uvw
+
+
+def ref_kat_tonemap(lin):
+    L = ref_lib(); lin = np.ascontiguousarray(lin, np.float32).reshape(-1, 3); n = lin.shape[0]
+    tone = np.empty((n, 3), np.float32); q = np.empty((n, 3), np.int32)
+    L.ref_kat_tonemap(C.c_uint32(n), _p(lin, _f32p), _p(tone, _f32p), _p(q, _i32p)); return tone, q

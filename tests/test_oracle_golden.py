@@ -1,0 +1,116 @@
+"""Pins the CPU restatement (oracle/srt_oracle.c) to the golden vectors produced by the compiled
+reference (tests/golden/make_golden.py).  CPU only.  Bit-exact everywhere: the restatement and the
+reference run the same IEEE ops and the same libm on the same host class."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from simple_raytracer_amd import abi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return gu.load_kat()
+
+
+def test_kat_ray_triangle(oracle, kat):
+    for pre in ("rt", "rt2"):
+        t = oracle.ray_triangle(kat[pre + "_ray"], kat[pre + "_tri"])
+        assert np.array_equal(bits(t), bits(kat[pre + "_t"]))
+    # the vectors really cover hits, misses, t == 0 and NaN
+    t = kat["rt_t"]
+    assert (t == -np.inf).sum() > 100 and (t > 0).sum() > 100 and np.isnan(t).sum() >= 1 and (t == 0).sum() >= 1
+
+
+def test_kat_ray_aabb(oracle, kat):
+    h = oracle.ray_aabb(kat["ab_ray"], kat["ab_box"])
+    assert np.array_equal(h, kat["ab_hit"])
+    assert 200 < h.sum() < h.size - 200
+    # intersectRayAabb (origin-0 form, :204-248) == NoOrigin form whenever the origin is 0
+    o0 = np.all(kat["ab_ray"][:, :3] == 0, axis=1)
+    assert np.array_equal(kat["ab_hit"][o0], kat["ab_hit_origin0"][o0])
+
+
+def test_kat_phong(oracle, kat):
+    assert np.array_equal(bits(oracle.phong(kat["ph_in"])), bits(kat["ph_rgb"]))
+
+
+def test_kat_barycentric(oracle, kat):
+    assert np.array_equal(bits(oracle.barycentric(kat["bc_in"])), bits(kat["bc_uvw"]))
+
+
+def test_kat_tonemap(oracle, kat):
+    tone, q = oracle.tonemap(kat["tm_lin"])
+    assert np.array_equal(bits(tone), bits(kat["tm_tone"]))
+    assert np.array_equal(q, kat["tm_q"])
+
+
+def test_light_staircase(oracle, kat):
+    tab = oracle.light_staircase(kat["ls_base"], 64)
+    assert np.array_equal(bits(tab), bits(kat["ls_table"]))
+    assert np.array_equal(bits(abi.light_staircase(kat["ls_base"], 64)), bits(kat["ls_table"]))
+    # sample i differs from sample i-1 on axis (i-1)%3 only
+    d = np.diff(tab, axis=0)
+    for i in range(63):
+        assert d[i, i % 3] > 0 and np.all(np.delete(d[i], i % 3) == 0)
+
+
+@pytest.mark.parametrize("name,W,H,L", gu.all_renders())
+def test_scene_matches_reference(oracle, name, W, H, L):
+    g = gu.GoldenScene(name)
+    o = oracle.render(g.flat, g.params(W, H, L))
+    assert np.array_equal(o["hit_id"], g.out(W, H, L, "hit_id")), "closest-hit ids differ from the reference"
+    assert np.array_equal(o["rgb8"], g.out(W, H, L, "rgb8")), "8-bit image differs from the reference"
+    assert gu.sha(o["t"]) == str(g.out(W, H, L, "sha_t"))
+    assert gu.sha(o["rgb_linear"]) == str(g.out(W, H, L, "sha_lin"))
+    assert gu.sha(o["rgb_tone"]) == str(g.out(W, H, L, "sha_tone"))
+    if g.out(W, H, L, "t") is not None:
+        assert np.array_equal(bits(o["t"]), bits(g.out(W, H, L, "t")))
+        assert np.array_equal(bits(o["rgb_linear"]), bits(g.out(W, H, L, "lin")))
+    st = o["stats"]
+    assert st["hit_rays"] == int((g.out(W, H, L, "hit_id") >= 0).sum())
+    assert st["shadow_rays"] == st["hit_rays"] * L and st["primary_rays"] == W * H
+
+
+def test_scanline_blocks_tile_the_frame(oracle):
+    """Block-cyclic scanline ownership (multi-GPU tiling): any split reassembles to the whole frame."""
+    g = gu.GoldenScene("cubes4_a0")
+    W, H, L = 128, 96, 8
+    whole = oracle.render(g.flat, g.params(W, H, L))
+    for world, rows in [(2, 8), (3, 5), (4, 16), (8, 7)]:
+        hit = np.full((H, W), -9, np.int32); rgb8 = np.zeros((H, W, 3), np.uint8); lin = np.zeros((H, W, 3), np.float32)
+        for rank in range(world):
+            o = oracle.render(g.flat, g.params(W, H, L, block_rows=rows, block_first=rank, block_stride=world))
+            ys = abi.rows_owned(H, rows, rank, world)
+            assert o["hit_id"].shape[0] == len(ys)
+            hit[ys] = o["hit_id"]; rgb8[ys] = o["rgb8"]; lin[ys] = o["rgb_linear"]
+        assert np.array_equal(hit, whole["hit_id"]) and np.array_equal(rgb8, whole["rgb8"])
+        assert np.array_equal(bits(lin), bits(whole["rgb_linear"]))
+
+
+def test_oracle_vs_live_reference_random_scenes(oracle):
+    """Where the compiled reference is present (this container), fuzz beyond the fixtures."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    import scenes
+    rng = np.random.default_rng(11)
+    for trial in range(3):
+        s = oracle.RefScene()
+        n_obj = 3
+        for k in range(n_obj):
+            n = int(rng.integers(1, 60))
+            c = rng.uniform(-60, 60, (n, 1, 3)).astype(np.float32); c[..., 2] += 260
+            pts = np.ones((n, 3, 4), np.float32); pts[..., :3] = c + rng.uniform(-30, 30, (n, 3, 3)).astype(np.float32)
+            s.add_object(f"o{k}", pts); s.set_color(f"o{k}", rng.uniform(0, 1, 3)); s.build_bvh(f"o{k}")
+        flat = s.export()
+        light = rng.uniform(-400, 400, 3).astype(np.float32)
+        W, H, L = 96, 64, 1 + trial
+        hit, t, tone, lin = s.trace(W, H, light, L)
+        o = oracle.render(flat, abi.make_params(W, H, abi.light_staircase(light, L)))
+        assert np.array_equal(o["hit_id"], hit)
+        assert np.array_equal(bits(o["t"]), bits(t)) and np.array_equal(bits(o["rgb_linear"]), bits(lin))
+        assert np.array_equal(bits(o["rgb_tone"]), bits(tone))
