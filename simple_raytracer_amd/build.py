@@ -1,0 +1,56 @@
+"""Builds the product's native code in-tree with hipcc for gfx950 (no JIT cache: the .so files travel
+with the repo snapshot to the GPU box).  `python -m simple_raytracer_amd.build` or build_all()."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_HIP = os.path.join(HERE, "libsrt_hip.so")
+
+# -ffp-contract=off is part of the numerical contract: FMA contraction changes hit results
+# (SURVEY.md H1).  Correctly rounded f32 divide / sqrt are hipcc defaults and must stay on.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "srt_hip.hip")]
+    deps = srcs + [os.path.join(CSRC, "srt_device.h"), os.path.join(HERE, "..", "include", "srt.h")]
+    if not force and not _stale(LIB_HIP, deps):
+        return LIB_HIP
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_HIP] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed for libsrt_hip.so")
+    if verbose and r.stderr:
+        print(r.stderr)
+    return LIB_HIP
+
+
+def build_all(force=False, verbose=False):
+    return [build_hip(force, verbose)]
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

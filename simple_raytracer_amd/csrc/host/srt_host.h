@@ -1,0 +1,145 @@
+// srt_host.h -- host-side C++ mirror of the reference's scene interface for the ray-trace path.
+//
+// The reference is compiled C++ with no plugin layer; the code either side of its hot path is
+// ObjectManager (Object.h:59-89, Object.cpp) and Transformation (Transformation.h:10-20).  This header
+// offers the same names, argument meanings and error behaviour on top of the C ABI (include/srt.h),
+// without glm / tinyobjloader / CImg, so that a scene script written against the reference's main()
+// (simple_raytracer.cpp:530-796) reads the same here:
+//
+//     srt_host::ObjectManager om;
+//     om.loadObjFile("cube.obj");
+//     om.transformTriangles("cube.obj", srt_host::Transformation::scaleObj(20, 20, 20));
+//     om.createBoundingHierarchy("cube.obj");
+//     srt_host::ImageData img = srt_host::sendRaysAndIntersectPointsColors({600, 400}, light, &om);
+//
+// Only sendRaysAndIntersectPointsColors touches the GPU (through srt_scene_create / srt_render).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/srt.h"
+
+namespace srt_host {
+
+struct vec2 { float x = 0, y = 0; vec2() = default; vec2(float a, float b) : x(a), y(b) {} };
+struct vec3 {
+    float x = 0, y = 0, z = 0;
+    vec3() = default; vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float& operator[](int i) { return (&x)[i]; } const float& operator[](int i) const { return (&x)[i]; }
+};
+struct vec4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    vec4() = default; vec4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    vec4(const vec3& v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    float& operator[](int i) { return (&x)[i]; } const float& operator[](int i) const { return (&x)[i]; }
+};
+struct ivec2 { int x = 0, y = 0; };
+// column-major 4x4, m[c][r] like glm::mat4
+struct mat4 {
+    vec4 c[4];
+    mat4() = default;
+    explicit mat4(float diag) { c[0].x = diag; c[1].y = diag; c[2].z = diag; c[3].w = diag; }
+    vec4& operator[](int i) { return c[i]; } const vec4& operator[](int i) const { return c[i]; }
+};
+vec4 operator*(const mat4& m, const vec4& v);      // glm type_mat4x4.inl:537-573 op order
+mat4 operator*(const mat4& a, const mat4& b);      // glm type_mat4x4.inl:660-705 op order
+mat4 inverse(const mat4& m);                       // glm func_matrix.inl:388-446 op order
+float radians(float degrees);                      // glm func_trigonometric.inl:9-14
+
+// Transformation.h:10-20 -- same eight factories, same matrices (incl. the reference's sign convention)
+class Transformation {
+public:
+    static mat4 scaleObj(float sx, float sy, float sz);
+    static mat4 rotateObjX(float degree);
+    static mat4 rotateObjY(float degree);
+    static mat4 rotateObjZ(float degree);
+    static mat4 mirrorObj(bool mirrorX, bool mirrorY, bool mirrorZ);
+    static mat4 shearObj(float shearXY, float shearXZ, float shearYX, float shearYZ, float shearZX, float shearZY);
+    static mat4 changeObjPosition(vec3 position);
+    static mat4 createViewMatrix(vec3 position, vec3 rotation);
+};
+
+// Object.h:15-36
+class Triangle {
+public:
+    vec4 pointOne, pointTwo, pointThree;
+    vec3 normalOne, normalTwo, normalThree;
+    vec2 colorOneCoordinate, colorTwoCoordinate, colorThreeCoordinate;
+    vec3 color;
+    std::string textureName;
+};
+
+// Object.h:38-44
+class Ray {
+public:
+    vec3 origin, direction;
+    explicit Ray(vec3 d) : origin(0.f, 0.f, 0.f), direction(d) {}
+};
+
+// Object.h:46-57, with the by-value triangle vectors replaced by a range into the object's
+// leaf-ordered index list (every inner node's triangles are a contiguous range of it).
+struct Node {
+    vec3 minBox, maxBox;
+    uint32_t first = 0, count = 0;     // range in ObjectManager::Hierarchy::order
+    int32_t left = -1, right = -1;     // indices into Hierarchy::nodes, -1 = none
+};
+
+struct Texture { std::vector<unsigned char> rgb; ivec2 dim; };
+
+// Object.h:59-89
+class ObjectManager {
+public:
+    struct Hierarchy { std::vector<Node> nodes; std::vector<uint32_t> order; };   // nodes[0] = root, DFS pre-order
+    std::unordered_map<std::string, vec3> minBox, maxBox;
+    std::unordered_map<std::string, vec3> objProperties;       // ambientStrength, specularStrength, shininess
+    std::unordered_map<std::string, std::vector<Triangle>> objTriangles;
+    std::unordered_map<std::string, Hierarchy> boundingVolumeHierarchy;
+    std::unordered_map<std::string, vec3> objColors;
+    std::unordered_map<std::string, Texture> textureData;      // + textureDimensions (Object.h:70-71)
+
+    void loadObjFile(const std::string& objFilename);                               // Object.cpp:25-170
+    const std::vector<Triangle>& getTriangles(const std::string& objFilename) const; // throws std::out_of_range (:174)
+    void setTriangles(const std::string& objFilename, const std::vector<Triangle>& triangles);
+    void transformTriangles(const std::string& objFilename, const mat4& matrix);    // Object.cpp:183-190
+    void createBoundingHierarchy(const std::string& objFilename);                   // Object.cpp:275-284
+    void setColor(const std::string& objFilename, const vec3& color);
+    vec3 getColor(const std::string& objFilename) const;                            // throws std::out_of_range (:292)
+};
+
+// The flat scene of include/srt.h built from an ObjectManager: objects in objTriangles iteration
+// order (what rayIntersection:409 walks), trees DFS left-first, triangles in visit order.
+struct FlatScene {
+    std::vector<float> node_min, node_max;
+    std::vector<int32_t> node_left, node_right, node_first, node_count;
+    std::vector<uint32_t> obj_root;
+    std::vector<float> tri_points, tri_texcoord, tri_normals;
+    std::vector<int32_t> tri_obj, tri_tex;
+    std::vector<float> obj_color, obj_material;
+    std::vector<uint8_t> tex_rgb; std::vector<uint64_t> tex_off; std::vector<uint32_t> tex_w, tex_h;
+    std::vector<std::string> names, tex_names;
+    srt_scene_desc desc() const;       // pointers into this object
+};
+// Throws std::runtime_error if an object has no hierarchy (the reference null-derefs there, :422).
+// A triangle whose textureName did not load (the reference null-derefs at :354-358) falls back to the
+// object colour (tri_tex = -1); SURVEY.md s8 f3.
+FlatScene flattenScene(ObjectManager* objManager);
+
+// simple_raytracer.cpp:28
+struct ImageData { std::vector<vec2> imagePoints; std::vector<vec3> imageColors; };
+
+// Drop-in for simple_raytracer.cpp:505-525: same signature shape, same result (hit pixels in the
+// reference's column-major emission order, colours as integer-valued floats), computed on HIP
+// device `device` through the C ABI.  lightAmount is the reference's hard-wired 1 (:445) by default.
+// Throws std::runtime_error carrying srt_strerror() on failure (the reference signals nothing).
+ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
+                                           int lightAmount = 1, int device = 0);
+
+// drawImage (:461-498) pixel contract: 8-bit RGB, every all-black pixel -> (173,216,230); written as
+// a 24-bit BMP like CImg::save_bmp.  displayImage is not supported (headless).
+void drawImage(const vec2& imgSize, const std::vector<vec2>& imagePoints, const std::vector<vec3>& imageColors,
+               const int& angleDegree, const bool& saveImage, const std::string& directory = "images/generation");
+void writeBmp(const std::string& path, uint32_t W, uint32_t H, const uint8_t* rgb /* H x W x 3, top-down */);
+
+} // namespace srt_host

@@ -1,0 +1,145 @@
+// srt_device.h -- device-side leaf math of the ray-trace path, hand-written for gfx950.
+//
+// Every function reproduces the float expression tree of one reference function exactly (IEEE f32,
+// no FMA contraction: the build passes -ffp-contract=off; correctly rounded divide / sqrt are hipcc's
+// default), because hit indices must be bit-exact against the reference.
+// Reference lines are in /root/reference/simple_raytracer.cpp; GLM expression trees in
+// library/glm-master/glm/detail/func_geometric.inl:48-55,73-83,98-105,120-125.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srt {
+
+// ---- device-resident records -------------------------------------------------------------------
+// Node: 32 B = two dwordx4.  Nodes are stored in DFS pre-order (left child of node i is i+1), all
+// objects concatenated in object order, so that "every node whose ancestors all pass the slab test"
+// (boundingBoxIntersection:296-317) is walked stacklessly:  i = pass ? i+1 : skip[i].
+struct __attribute__((aligned(16))) DevNode {
+    float minx, miny, minz, maxx;
+    float maxy, maxz;
+    int32_t skip;      // index of the first node after this node's subtree
+    int32_t leaf;      // -1 inner; else (first_triangle << 5) | count
+};
+static_assert(sizeof(DevNode) == 32, "node record is 32 B");
+
+// Triangle: 48 B = three dwordx4: ray-independent prefix of rayTriangleIntersection:45-51
+// (P1 = p1/w, e1 = P2-P1, e2 = P3-P1: 36 B, what a Moller-Trumbore test reads) followed by the flat
+// face normal of calculateTriangleNormal:32-37 (12 B, read once per shaded hit).
+struct __attribute__((aligned(16))) DevTri {
+    float p1x, p1y, p1z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z, nx, ny, nz;
+};
+static_assert(sizeof(DevTri) == 48, "triangle record is 48 B");
+
+constexpr int LEAF_SHIFT = 5;
+constexpr int LEAF_MAX = (1 << LEAF_SHIFT) - 1;
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// glm::dot(vec3): (x + y) + z
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// glm::cross
+__device__ __forceinline__ V3 cross3(V3 x, V3 y) {
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+// glm::normalize = v * (1 / sqrt(dot(v, v)))
+__device__ __forceinline__ V3 normalize3(V3 v) { float s = 1.0f / sqrtf(dot3(v, v)); return v * s; }
+// glm::max(x, y) = (x < y) ? y : x   (NaN-asymmetric on purpose)
+__device__ __forceinline__ float glm_max(float x, float y) { return (x < y) ? y : x; }
+
+#define SRT_NEG_INF (-__builtin_inff())
+
+// ---- a4: intersectRayAabbNoOrigin, simple_raytracer.cpp:252-293 ---------------------------------
+// Comparison for comparison (x/0 = +-inf, 0/0 = NaN must fall through the same way): no fmin/fmax.
+__device__ __forceinline__ bool ray_aabb(V3 o, V3 d, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+    float minX = (mnx - o.x) / d.x, maxX = (mxx - o.x) / d.x;
+    if (minX > maxX) { float s = minX; minX = maxX; maxX = s; }
+    float minY = (mny - o.y) / d.y, maxY = (mxy - o.y) / d.y;
+    if (minY > maxY) { float s = minY; minY = maxY; maxY = s; }
+    if (maxX < minY || maxY < minX) return false;
+    if (minY > minX) minX = minY;
+    if (maxY < maxX) maxX = maxY;
+    float minZ = (mnz - o.z) / d.z, maxZ = (mxz - o.z) / d.z;
+    if (minZ > maxZ) { float s = minZ; minZ = maxZ; maxZ = s; }
+    if ((minX > maxZ) || (minZ > maxX)) return false;
+    return true;
+}
+
+// ---- a5: rayTriangleIntersection, simple_raytracer.cpp:42-75 (Moller-Trumbore) ------------------
+// Returns -inf on a miss, t >= 0 on a hit, NaN when NaN falls through every test (as the reference).
+__device__ __forceinline__ float ray_triangle(V3 o, V3 d, V3 p1, V3 e1, V3 e2) {
+    V3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (__builtin_fabsf(det) < 1e-12f) return SRT_NEG_INF;
+    float inv = 1.0f / det;
+    V3 tvec = o - p1;
+    float u = dot3(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) return SRT_NEG_INF;
+    V3 qvec = cross3(tvec, e1);
+    float v = dot3(d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) return SRT_NEG_INF;
+    float t = dot3(e2, qvec) * inv;
+    if (t < 0.0f) return SRT_NEG_INF;
+    return t;
+}
+
+// ---- a8b: calculateBarycentricCoords :79-117 ------------------------------------------------------
+__device__ __forceinline__ V3 barycentric(V3 p1, V3 e1, V3 e2, V3 point) {
+    V3 v2 = point - p1;
+    float d00 = dot3(e1, e1), d01 = dot3(e1, e2), d11 = dot3(e2, e2);
+    float d20 = dot3(v2, e1), d21 = dot3(v2, e2);
+    float denom = d00 * d11 - d01 * d01;
+    float v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    float u = 1.0f - v - w;
+    return mk(u, v, w);
+}
+
+// powf as the host libm computes it: glibc's powf is correctly rounded in all but a vanishing
+// fraction of cases; evaluating in f64 and rounding once gets the same bits far more often than
+// OCML's f32 pow (<= 1 ulp) would.  The only host<->device op that is not bit-pinned.
+__device__ __forceinline__ float pow_like_host(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// ---- a8: phongIllumination :144-200, lightColor = (1,1,1) (:433) ---------------------------------
+__device__ __forceinline__ V3 phong(V3 n, V3 o, V3 d, V3 L, V3 objColor, float ka, float ks, float shin, float t) {
+    const float rView = 1.0f / 3.14159265358979323846264338327950288f;
+    const float lc = 1.0f;
+    V3 P = o + d * t;
+    V3 l = normalize3(L - P);
+    float dp = dot3(n, l);
+    if (dp < 0.0f) dp = -dp;
+    float m = glm_max(dp, 0.0f);
+    V3 diffuse = mk(((rView * objColor.x) * lc) * m, ((rView * objColor.y) * lc) * m, ((rView * objColor.z) * lc) * m);
+    float ak = rView * ka;
+    V3 ambient = mk((ak * objColor.x) * lc, (ak * objColor.y) * lc, (ak * objColor.z) * lc);
+    V3 v = normalize3(neg(d));
+    V3 I = neg(l);
+    float ndi = dot3(n, I);
+    V3 r = mk(I.x - (n.x * ndi) * 2.0f, I.y - (n.y * ndi) * 2.0f, I.z - (n.z * ndi) * 2.0f);
+    float sp = pow_like_host(glm_max(dot3(r, v), 0.0f), shin);
+    float s1 = ((lc * ks) * m) * sp;
+    return mk((diffuse.x + s1) + ambient.x, (diffuse.y + s1) + ambient.y, (diffuse.z + s1) + ambient.z);
+}
+
+// ---- a9: Reinhard + gamma (:391-398), quantiser (:447-449) ----------------------------------------
+__device__ __forceinline__ float tone1(float c, float reinhard, float gamma) {
+    c = c / (c + reinhard);
+    return pow_like_host(c, gamma);
+}
+// int(c*255), truncation.  NaN / out-of-range is UB in the reference; defined as clamp, NaN -> 0
+// (identical to the oracle's quant1).
+__device__ __forceinline__ int quant1(float c) {
+    float s = c * 255.0f;
+    if (!(s > 0.0f)) return 0;
+    if (s >= 255.0f) return 255;
+    return (int)s;
+}
+
+} // namespace srt

@@ -1,0 +1,600 @@
+// srt_hip.hip -- HIP kernels (gfx950) and the extern "C" ABI of include/srt.h.
+//
+// Path replaced: sendRaysAndIntersectPointsColors -> rayIntersection -> boundingBoxIntersection /
+// intersectRayAabbNoOrigin -> rayTriangleIntersection -> softShadow -> shadowIntersection +
+// phongIllumination (/root/reference/simple_raytracer.cpp:505-525, 405-457, 296-317, 252-293, 42-75,
+// 348-401, 321-342, 144-200).  No CPU fallback exists in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/srt.h"
+#include "srt_device.h"
+
+using namespace srt;
+
+// =================================================================================================
+// Device-side scene / params views (passed by value in kernarg SGPRs)
+// =================================================================================================
+struct DevScene {
+    const DevNode* nodes;
+    const DevTri* tris;
+    const int32_t* tri_obj;
+    const int32_t* tri_tex;       // may be null (no textures)
+    const float* tri_tc;          // n_tris x 6, may be null
+    const float* obj_color;       // n_objects x 3
+    const float* obj_mat;         // n_objects x 3
+    const int2* obj_range;        // n_objects: [first node, end node) in pre-order
+    const uint8_t* tex;
+    const unsigned long long* tex_off;
+    const uint32_t* tex_w;
+    const uint32_t* tex_h;
+    const unsigned long long* tex_size;
+    uint32_t n_nodes, n_tris, n_objects;
+};
+
+struct DevParams {
+    uint32_t W, H, rows;
+    uint32_t block_rows, block_first, block_stride;
+    int32_t i0, j0;
+    float focal;
+    uint32_t n_lights;
+    const float* lights;          // device, n_lights x 3
+    float shadow_div, reinhard, gamma;
+    uint32_t bg;                  // r | g << 8 | b << 16
+};
+
+// counters[0] hit pixels, [1] node tests, [2] triangle tests
+__device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
+// a wave are neighbours, so they walk the same top-of-tree nodes (loads of one node by many lanes
+// coalesce into one 32 B fetch) and diverge only deep in the tree.
+__device__ __forceinline__ bool tile_pixel(const DevParams& p, uint32_t& px, uint32_t& r) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    r  = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    return px < p.W && r < p.rows;
+}
+// local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
+__device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
+    return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
+}
+// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
+__device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
+    return mk((float)(p.i0 + (int)px) + 0.0f, (float)(p.j0 + (int)y) + 0.0f, p.focal);
+}
+
+// =================================================================================================
+// Kernel 1: closest hit.  rayIntersection:405-431 with boundingBoxIntersection:296-317 fused in:
+// walk ALL slab-passing nodes of ALL objects in pre-order (== reference visit order), test leaf
+// triangles in stored order, strict '<' keeps the first (lowest id) of equal t.  No t-pruning: the
+// reference has none and its slab test may cull what Moller-Trumbore would hit, so the candidate
+// set must be reproduced exactly.
+// =================================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_closest_hit(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+                                                     float* __restrict__ t_out, unsigned long long* __restrict__ counters) {
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    unsigned long long n_node = 0, n_tri = 0;
+    float best = __builtin_inff();
+    int32_t best_id = -1;
+    if (live) {
+        const V3 o = mk(0.0f, 0.0f, 0.0f);
+        const V3 d = primary_dir(p, px, image_row(p, r));
+        const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+        const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+        int32_t i = 0;
+        const int32_t n = (int32_t)s.n_nodes;
+        while (i < n) {
+            const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+            const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+            if (COUNT) n_node++;
+            if (ray_aabb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                if (leaf >= 0) {
+                    const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
+                    for (int32_t k = 0; k < cnt; k++) {
+                        const size_t ti = (size_t)(first + k) * 3;
+                        const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                        const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                        if (COUNT) n_tri++;
+                        const float t = ray_triangle(o, d, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                        if (t != SRT_NEG_INF && t < best) { best = t; best_id = first + k; }
+                    }
+                }
+                i = i + 1;
+            } else {
+                i = skip;
+            }
+        }
+        const size_t pix = (size_t)r * p.W + px;
+        hit_id[pix] = best_id;
+        t_out[pix] = best;
+    }
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
+// Kernel 2: shadow rays + shading + tone map.  softShadow:348-401 -> shadowIntersection:321-342 +
+// phongIllumination:144-200, then the quantiser (:447-449) and the black -> background rule
+// (:518, drawImage:476-487).  Shading runs once, for the closest hit (the reference re-shades every
+// improving hit and keeps the last: same value).  The hit object's own tree is skipped (the reference
+// walks it and discards the result, :328/:331) and the any-hit walk exits at the first hit.
+// =================================================================================================
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit(const DevScene& s, int32_t self_obj, V3 so, V3 sd,
+                                        unsigned long long& n_node, unsigned long long& n_tri) {
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    const int2 self = s.obj_range[self_obj];
+    int32_t i = 0;
+    const int32_t n = (int32_t)s.n_nodes;
+    while (i < n) {
+        if (i == self.x) { i = self.y; continue; }
+        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+        const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+        if (COUNT) n_node++;
+        if (ray_aabb(so, sd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+            if (leaf >= 0) {
+                const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
+                for (int32_t k = 0; k < cnt; k++) {
+                    const size_t ti = (size_t)(first + k) * 3;
+                    const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                    const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                    if (COUNT) n_tri++;
+                    const float t = ray_triangle(so, sd, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                    if (t != SRT_NEG_INF) return true;       // any t >= 0, NaN included (:335)
+                }
+            }
+            i = i + 1;
+        } else {
+            i = skip;
+        }
+    }
+    return false;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                               const float* __restrict__ t_in, float* __restrict__ rgb_linear,
+                                               uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    unsigned long long n_node = 0, n_tri = 0;
+    bool is_hit = false;
+    if (live) {
+        const size_t pix = (size_t)r * p.W + px;
+        const int32_t id = hit_id[pix];
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        int q0 = 0, q1 = 0, q2 = 0;
+        if (id >= 0) {
+            is_hit = true;
+            const float t = t_in[pix];
+            const V3 o = mk(0.0f, 0.0f, 0.0f);
+            const V3 d = primary_dir(p, px, image_row(p, r));
+            const int32_t obj = s.tri_obj[id];
+            const float4* tp = reinterpret_cast<const float4*>(s.tris) + (size_t)id * 3;
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const V3 nrm = mk(t2.y, t2.z, t2.w);
+            V3 color = mk(s.obj_color[obj * 3], s.obj_color[obj * 3 + 1], s.obj_color[obj * 3 + 2]);     // :437-440
+            const int32_t tex = s.tri_tex ? s.tri_tex[id] : -1;
+            if (tex >= 0) {                                                                             // :350-361
+                const V3 P = o + d * t;
+                const V3 bc = barycentric(mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, t2.x), P);
+                const float* tc = s.tri_tc + (size_t)id * 6;
+                const float tx = (bc.x * tc[0] + bc.y * tc[2]) + bc.z * tc[4];                          // :123-125
+                const float ty = (bc.x * tc[1] + bc.y * tc[3]) + bc.z * tc[5];
+                long long idx = ((long long)((int)ty * (int)s.tex_w[tex] + (int)tx)) * 3;               // :357
+                // the reference reads out of bounds here if the texel index leaves the image (UB);
+                // this kernel clamps into the texture instead of faulting
+                const long long last = (long long)s.tex_size[tex] - 3;
+                idx = idx < 0 ? 0 : (idx > last ? last : idx);
+                const uint8_t* td = s.tex + s.tex_off[tex] + idx;
+                color = mk(td[0] / 255.0f, td[1] / 255.0f, td[2] / 255.0f);
+            }
+            const float ka = s.obj_mat[obj * 3], ks = s.obj_mat[obj * 3 + 1], sh = s.obj_mat[obj * 3 + 2];
+            const V3 dt = d * t;                      // shadowIntersection:325-326: origin d*t, dir L - d*t
+            for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
+                const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
+                const bool shadowed = any_hit<COUNT>(s, obj, dt, L - dt, n_node, n_tri);
+                V3 c = phong(nrm, o, d, L, color, ka, ks, sh, t);
+                if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
+                sum = sum + c;                                                                          // :370
+            }
+            q0 = quant1(tone1(sum.x, p.reinhard, p.gamma));                                             // :391-398,447-449
+            q1 = quant1(tone1(sum.y, p.reinhard, p.gamma));
+            q2 = quant1(tone1(sum.z, p.reinhard, p.gamma));
+        }
+        if (rgb_linear) { rgb_linear[pix * 3] = sum.x; rgb_linear[pix * 3 + 1] = sum.y; rgb_linear[pix * 3 + 2] = sum.z; }
+        if (rgb8) {
+            if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
+            rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
+        }
+    }
+    wave_add(counters + 0, is_hit ? 1ull : 0ull);
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
+// Host side of the ABI
+// =================================================================================================
+static thread_local int g_last_hip = 0;
+#define HIP_TRY(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return SRT_ERR_DEVICE; } \
+    } while (0)
+
+struct srt_scene {
+    int device = 0;
+    DevScene dev{};
+    std::vector<void*> allocs;
+    uint64_t bytes = 0;
+    // workspace
+    int32_t* ws_hit = nullptr; float* ws_t = nullptr; size_t ws_pixels = 0;
+    float* ws_lin = nullptr; uint8_t* ws_rgb8 = nullptr; size_t ws_out_pixels = 0;
+    float* d_lights = nullptr; float* h_lights = nullptr; uint32_t lights_cap = 0, lights_valid = 0;
+    unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    srt_stats last{};
+};
+
+template <typename T>
+static int upload(srt_scene* s, const T* host, size_t n, const T** out) {
+    void* d = nullptr;
+    size_t bytes = sizeof(T) * (n ? n : 1);
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (n) HIP_TRY(hipMemcpy(d, host, sizeof(T) * n, hipMemcpyHostToDevice));
+    s->bytes += bytes;
+    *out = (const T*)d;
+    return SRT_OK;
+}
+
+// Ray-independent prefix of rayTriangleIntersection:45-51 and calculateTriangleNormal:32-37,
+// evaluated on the host with the same IEEE ops (this TU is built with -ffp-contract=off).
+static DevTri derive_triangle(const float* p) {
+    DevTri t;
+    const float P1x = p[0] / p[3], P1y = p[1] / p[3], P1z = p[2] / p[3];
+    const float P2x = p[4] / p[7], P2y = p[5] / p[7], P2z = p[6] / p[7];
+    const float P3x = p[8] / p[11], P3y = p[9] / p[11], P3z = p[10] / p[11];
+    t.p1x = P1x; t.p1y = P1y; t.p1z = P1z;
+    t.e1x = P2x - P1x; t.e1y = P2y - P1y; t.e1z = P2z - P1z;
+    t.e2x = P3x - P1x; t.e2y = P3y - P1y; t.e2z = P3z - P1z;
+    const float ax = p[4] - p[0], ay = p[5] - p[1], az = p[6] - p[2];       // raw xyz, no w-divide (:33-34)
+    const float bx = p[8] - p[0], by = p[9] - p[1], bz = p[10] - p[2];
+    const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+    const float s = 1.0f / std::sqrt((cx * cx + cy * cy) + cz * cz);
+    t.nx = cx * s; t.ny = cy * s; t.nz = cz * s;
+    return t;
+}
+
+extern "C" {
+
+uint32_t srt_abi_version(void) { return SRT_ABI_VERSION; }
+int srt_last_hip_error(void) { return g_last_hip; }
+
+const char* srt_strerror(int code) {
+    switch (code) {
+    case SRT_OK: return "ok";
+    case SRT_ERR_ARG: return "invalid argument";
+    case SRT_ERR_LAYOUT: return "scene arrays violate the layout contract of include/srt.h";
+    case SRT_ERR_DEVICE: return "HIP runtime error (see srt_last_hip_error)";
+    case SRT_ERR_NO_GPU: return "no HIP device: this library has no CPU fallback";
+    case SRT_ERR_TEXTURE: return "triangle references a texture that does not exist";
+    case SRT_ERR_LIMIT: return "size exceeds an implementation limit";
+    default: return "unknown error";
+    }
+}
+
+void srt_params_default(srt_params* p, uint32_t width, uint32_t height) {
+    std::memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height;
+    p->block_rows = height; p->block_first = 0; p->block_stride = 1;
+    p->focal = 400.0f;                 // simple_raytracer.cpp:506
+    p->n_lights = 1;                   // :445
+    p->light_pos = nullptr;
+    p->shadow_div = 5.0f;              // :369
+    p->reinhard = 0.5f;                // :391
+    p->gamma = 1.1f;                   // :396
+    p->background[0] = 173; p->background[1] = 216; p->background[2] = 230;   // :476
+    p->spp = 1; p->flags = 0;
+}
+
+void srt_light_staircase(const float base[3], uint32_t n, float* out) {
+    float L[3] = { base[0], base[1], base[2] };          // softShadow:363
+    for (uint32_t i = 0; i < n; i++) {
+        out[i * 3] = L[0]; out[i * 3 + 1] = L[1]; out[i * 3 + 2] = L[2];
+        L[i % 3] += 3.0f;                                 // :372-382
+    }
+}
+
+uint32_t srt_rows_owned(const srt_params* p) {
+    if (!p || !p->block_rows || !p->block_stride) return 0;
+    const uint32_t nblocks = (p->height + p->block_rows - 1) / p->block_rows;
+    uint32_t rows = 0;
+    for (uint32_t b = p->block_first; b < nblocks; b += p->block_stride) {
+        const uint32_t y0 = b * p->block_rows;
+        uint32_t y1 = y0 + p->block_rows;
+        if (y1 > p->height) y1 = p->height;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+int srt_scene_destroy(srt_scene* s) {
+    if (!s) return SRT_ERR_ARG;
+    (void)hipSetDevice(s->device);
+    if (s->pending) (void)hipEventSynchronize(s->ev[2]);
+    for (void* d : s->allocs) (void)hipFree(d);
+    if (s->ws_hit) (void)hipFree(s->ws_hit);
+    if (s->ws_t) (void)hipFree(s->ws_t);
+    if (s->ws_lin) (void)hipFree(s->ws_lin);
+    if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
+    if (s->d_lights) (void)hipFree(s->d_lights);
+    if (s->h_lights) (void)hipHostFree(s->h_lights);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+    return SRT_OK;
+}
+
+// Validate the layout contract and rewrite the trees in DFS pre-order with skip links.
+static int build_device_records(const srt_scene_desc* d, std::vector<DevNode>& nodes, std::vector<int2>& ranges) {
+    const uint32_t N = d->n_nodes;
+    nodes.clear(); nodes.reserve(N); ranges.resize(d->n_objects);
+    std::vector<uint8_t> seen(N, 0);
+    int64_t tri_cursor = 0;
+    // explicit DFS stack: state 0 = emit node, 1 = left subtree done, 2 = right subtree done
+    struct Item { int32_t orig; int32_t emitted; int state; };
+    std::vector<Item> st;
+    for (uint32_t k = 0; k < d->n_objects; k++) {
+        const uint32_t root = d->obj_root[k];
+        if (root >= N) return SRT_ERR_LAYOUT;
+        ranges[k].x = (int32_t)nodes.size();
+        st.clear(); st.push_back({ (int32_t)root, -1, 0 });
+        while (!st.empty()) {
+            Item& it = st.back();        // not used after a push_back below
+            if (it.state == 0) {
+                if (it.orig < 0 || (uint32_t)it.orig >= N || seen[it.orig]) return SRT_ERR_LAYOUT;
+                seen[it.orig] = 1;
+                const int32_t l = d->node_left[it.orig], r = d->node_right[it.orig];
+                DevNode dn;
+                dn.minx = d->node_min[3 * (size_t)it.orig]; dn.miny = d->node_min[3 * (size_t)it.orig + 1]; dn.minz = d->node_min[3 * (size_t)it.orig + 2];
+                dn.maxx = d->node_max[3 * (size_t)it.orig]; dn.maxy = d->node_max[3 * (size_t)it.orig + 1]; dn.maxz = d->node_max[3 * (size_t)it.orig + 2];
+                dn.skip = -1; dn.leaf = -1;
+                it.emitted = (int32_t)nodes.size();
+                if (l < 0 && r < 0) {
+                    const int32_t first = d->node_first[it.orig], cnt = d->node_count[it.orig];
+                    if (cnt < 0 || (cnt > 0 && first != tri_cursor) || tri_cursor + cnt > (int64_t)d->n_tris) return SRT_ERR_LAYOUT;
+                    if (cnt > LEAF_MAX) return SRT_ERR_LIMIT;
+                    for (int32_t j = 0; j < cnt; j++) if (d->tri_obj[tri_cursor + j] != (int32_t)k) return SRT_ERR_LAYOUT;
+                    dn.leaf = (int32_t)((tri_cursor << LEAF_SHIFT) | cnt);
+                    tri_cursor += cnt;
+                    dn.skip = it.emitted + 1;
+                    nodes.push_back(dn);
+                    st.pop_back();
+                } else {
+                    if (l < 0 || r < 0) return SRT_ERR_LAYOUT;      // the reference's trees are full binary
+                    nodes.push_back(dn);
+                    it.state = 1;
+                    st.push_back({ l, -1, 0 });
+                }
+            } else if (it.state == 1) {
+                it.state = 2;
+                const int32_t r = d->node_right[it.orig];
+                st.push_back({ r, -1, 0 });
+            } else {
+                nodes[it.emitted].skip = (int32_t)nodes.size();
+                st.pop_back();
+            }
+        }
+        ranges[k].y = (int32_t)nodes.size();
+    }
+    if (nodes.size() != N || tri_cursor != (int64_t)d->n_tris) return SRT_ERR_LAYOUT;
+    return SRT_OK;
+}
+
+int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
+    if (!d || !out) return SRT_ERR_ARG;
+    *out = nullptr;
+    if (!d->n_objects || !d->n_nodes || !d->node_min || !d->node_max || !d->node_left || !d->node_right ||
+        !d->node_first || !d->node_count || !d->obj_root || !d->obj_color || !d->obj_material) return SRT_ERR_ARG;
+    if (d->n_tris && (!d->tri_points || !d->tri_obj)) return SRT_ERR_ARG;
+    if (d->n_tris >= (1u << (31 - LEAF_SHIFT)) || d->n_nodes >= (1u << 30)) return SRT_ERR_LIMIT;
+    if (d->n_textures && (!d->tex_rgb || !d->tex_off || !d->tex_w || !d->tex_h || !d->tri_tex || !d->tri_texcoord)) return SRT_ERR_ARG;
+    for (uint32_t i = 0; i < d->n_tris; i++) {
+        if (d->tri_obj[i] < 0 || (uint32_t)d->tri_obj[i] >= d->n_objects) return SRT_ERR_LAYOUT;
+        if (d->tri_tex && d->tri_tex[i] >= (int32_t)d->n_textures) return SRT_ERR_TEXTURE;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SRT_ERR_NO_GPU;
+    if (device < 0 || device >= ndev) return SRT_ERR_ARG;
+
+    std::vector<DevNode> nodes; std::vector<int2> ranges;
+    int rc = build_device_records(d, nodes, ranges);
+    if (rc != SRT_OK) return rc;
+    std::vector<DevTri> tris(d->n_tris);
+    for (uint32_t i = 0; i < d->n_tris; i++) tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i);
+
+    HIP_TRY(hipSetDevice(device));
+    srt_scene* s = new (std::nothrow) srt_scene();
+    if (!s) return SRT_ERR_ARG;
+    s->device = device;
+    #define UP(expr) do { rc = (expr); if (rc != SRT_OK) { srt_scene_destroy(s); return rc; } } while (0)
+    UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
+    UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
+    UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
+    UP(upload(s, ranges.data(), ranges.size(), &s->dev.obj_range));
+    UP(upload(s, d->obj_color, (size_t)d->n_objects * 3, &s->dev.obj_color));
+    UP(upload(s, d->obj_material, (size_t)d->n_objects * 3, &s->dev.obj_mat));
+    bool any_tex = false;
+    if (d->n_textures && d->tri_tex) for (uint32_t i = 0; i < d->n_tris; i++) any_tex |= d->tri_tex[i] >= 0;
+    if (any_tex) {
+        std::vector<unsigned long long> off(d->n_textures), size(d->n_textures);
+        unsigned long long total = 0;
+        for (uint32_t k = 0; k < d->n_textures; k++) {
+            off[k] = d->tex_off[k]; size[k] = (unsigned long long)d->tex_w[k] * d->tex_h[k] * 3;
+            if (size[k] < 3) { srt_scene_destroy(s); return SRT_ERR_TEXTURE; }
+            if (off[k] + size[k] > total) total = off[k] + size[k];
+        }
+        UP(upload(s, d->tri_tex, d->n_tris, &s->dev.tri_tex));
+        UP(upload(s, d->tri_texcoord, (size_t)d->n_tris * 6, &s->dev.tri_tc));
+        UP(upload(s, d->tex_rgb, (size_t)total, &s->dev.tex));
+        UP(upload(s, off.data(), off.size(), &s->dev.tex_off));
+        UP(upload(s, size.data(), size.size(), &s->dev.tex_size));
+        UP(upload(s, d->tex_w, d->n_textures, &s->dev.tex_w));
+        UP(upload(s, d->tex_h, d->n_textures, &s->dev.tex_h));
+    }
+    #undef UP
+    s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
+    hipError_t e = hipMalloc((void**)&s->d_counters, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+    if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
+    *out = s;
+    return SRT_OK;
+}
+
+uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
+
+static int check_params(const srt_params* p) {
+    if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
+    if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
+    if (p->spp != 1) return SRT_ERR_ARG;            // spp > 1 is an extension not built yet
+    if (p->flags & SRT_FLAG_SMOOTH_NORMALS) return SRT_ERR_ARG;   // s8 f2, not built yet
+    if ((uint64_t)p->width * p->height >= (1ull << 31)) return SRT_ERR_LIMIT;
+    return SRT_OK;
+}
+
+int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t* d_hit_id, float* d_t,
+                      float* d_rgb_linear, uint8_t* d_rgb8) {
+    if (!s) return SRT_ERR_ARG;
+    int rc = check_params(p);
+    if (rc != SRT_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t rows = srt_rows_owned(p);
+    std::memset(&s->last, 0, sizeof(s->last));
+    s->last.rows = rows;
+    s->last.primary_rays = (uint64_t)p->width * rows;
+    if (!rows) { s->pending = false; return SRT_OK; }
+    const size_t pixels = (size_t)p->width * rows;
+    // workspace for hit ids / t when the caller does not want them (the shade kernel does)
+    if ((!d_hit_id || !d_t) && s->ws_pixels < pixels) {
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->ws_hit) (void)hipFree(s->ws_hit);
+        if (s->ws_t) (void)hipFree(s->ws_t);
+        s->ws_hit = nullptr; s->ws_t = nullptr; s->ws_pixels = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws_hit, pixels * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void**)&s->ws_t, pixels * sizeof(float)));
+        s->ws_pixels = pixels;
+    }
+    if (!d_hit_id) d_hit_id = s->ws_hit;
+    if (!d_t) d_t = s->ws_t;
+    if (p->n_lights > s->lights_cap) {
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->d_lights) (void)hipFree(s->d_lights);
+        if (s->h_lights) (void)hipHostFree(s->h_lights);
+        s->d_lights = nullptr; s->h_lights = nullptr; s->lights_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_lights, (size_t)p->n_lights * 3 * sizeof(float)));
+        HIP_TRY(hipHostMalloc((void**)&s->h_lights, (size_t)p->n_lights * 3 * sizeof(float), hipHostMallocDefault));
+        s->lights_cap = p->n_lights; s->lights_valid = 0;
+    }
+    const size_t light_bytes = (size_t)p->n_lights * 3 * sizeof(float);
+    if (p->n_lights && !(s->lights_valid == p->n_lights && std::memcmp(s->h_lights, p->light_pos, light_bytes) == 0)) {
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));     // staging buffer still in flight
+        std::memcpy(s->h_lights, p->light_pos, light_bytes);
+        HIP_TRY(hipMemcpyAsync(s->d_lights, s->h_lights, light_bytes, hipMemcpyHostToDevice, stream));
+        s->lights_valid = p->n_lights;
+    }
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+
+    DevParams dp;
+    dp.W = p->width; dp.H = p->height; dp.rows = rows;
+    dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
+    dp.i0 = (int)(-(float)p->width / 2); dp.j0 = (int)(-(float)p->height / 2);       // :511,513
+    dp.focal = p->focal; dp.n_lights = p->n_lights; dp.lights = s->d_lights;
+    dp.shadow_div = p->shadow_div; dp.reinhard = p->reinhard; dp.gamma = p->gamma;
+    dp.bg = (uint32_t)p->background[0] | ((uint32_t)p->background[1] << 8) | ((uint32_t)p->background[2] << 16);
+
+    const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
+    const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
+    HIP_TRY(hipEventRecord(s->ev[0], stream));
+    if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
+    else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[1], stream));
+    if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+    else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[2], stream));
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    s->last_stream = stream;
+    s->pending = true;
+    s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
+    return SRT_OK;
+}
+
+int srt_sync(srt_scene* s, srt_stats* stats) {
+    if (!s) return SRT_ERR_ARG;
+    if (s->pending) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&c, s->ev[0], s->ev[2]));
+        s->last.ms_primary = a; s->last.ms_shade = b; s->last.ms_total = c;
+        s->last.hit_rays = s->h_counters[0];
+        s->last.shadow_rays = s->last.shadow_rays * s->h_counters[0];
+        s->last.node_tests = s->h_counters[1];
+        s->last.tri_tests = s->h_counters[2];
+        s->pending = false;
+    }
+    if (stats) *stats = s->last;
+    return SRT_OK;
+}
+
+int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, srt_stats* stats) {
+    if (!s) return SRT_ERR_ARG;
+    int rc = check_params(p);
+    if (rc != SRT_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t rows = srt_rows_owned(p);
+    const size_t pixels = (size_t)p->width * rows;
+    if (pixels > s->ws_out_pixels) {
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->ws_lin) (void)hipFree(s->ws_lin);
+        if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
+        s->ws_lin = nullptr; s->ws_rgb8 = nullptr; s->ws_out_pixels = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws_lin, pixels * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s->ws_rgb8, pixels * 3));
+        s->ws_out_pixels = pixels;
+    }
+    rc = srt_render_device(s, p, nullptr, nullptr, nullptr, rgb_linear ? s->ws_lin : nullptr, rgb8 ? s->ws_rgb8 : nullptr);
+    if (rc != SRT_OK) return rc;
+    rc = srt_sync(s, stats);
+    if (rc != SRT_OK) return rc;
+    if (pixels) {
+        if (hit_id) HIP_TRY(hipMemcpy(hit_id, s->ws_hit, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (t) HIP_TRY(hipMemcpy(t, s->ws_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgb_linear) HIP_TRY(hipMemcpy(rgb_linear, s->ws_lin, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (rgb8) HIP_TRY(hipMemcpy(rgb8, s->ws_rgb8, pixels * 3, hipMemcpyDeviceToHost));
+    }
+    return SRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,127 @@
+"""ctypes binding of the C ABI in include/srt.h (libsrt_hip.so).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is visible, this
+raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
+
+# every symbol include/srt.h declares
+ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_scene_create", "srt_scene_destroy",
+               "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
+               "srt_last_hip_error", "srt_abi_version")
+
+_f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+_lib = None
+
+
+class SrtError(RuntimeError):
+    def __init__(self, code, where):
+        L = load()
+        msg = L.srt_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code}, hip error {L.srt_last_hip_error()})")
+        self.code = code
+
+
+def load():
+    """Load libsrt_hip.so; fail loudly if it has not been built (python -m simple_raytracer_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension must be built "
+                               "(python -m simple_raytracer_amd.build); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.srt_params_default.argtypes = [C.POINTER(abi.Params), C.c_uint32, C.c_uint32]
+        L.srt_params_default.restype = None
+        L.srt_light_staircase.argtypes = [_f32p, C.c_uint32, _f32p]
+        L.srt_light_staircase.restype = None
+        L.srt_rows_owned.argtypes = [C.POINTER(abi.Params)]
+        L.srt_rows_owned.restype = C.c_uint32
+        L.srt_scene_create.argtypes = [C.c_int, C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
+        L.srt_scene_create.restype = C.c_int
+        L.srt_scene_destroy.argtypes = [C.c_void_p]
+        L.srt_scene_destroy.restype = C.c_int
+        L.srt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srt_render_device.restype = C.c_int
+        L.srt_render.argtypes = [C.c_void_p, C.POINTER(abi.Params), _i32p, _f32p, _f32p, _u8p, C.POINTER(abi.Stats)]
+        L.srt_render.restype = C.c_int
+        L.srt_sync.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
+        L.srt_sync.restype = C.c_int
+        L.srt_scene_device_bytes.argtypes = [C.c_void_p]
+        L.srt_scene_device_bytes.restype = C.c_uint64
+        L.srt_strerror.argtypes = [C.c_int]
+        L.srt_strerror.restype = C.c_char_p
+        L.srt_last_hip_error.restype = C.c_int
+        L.srt_abi_version.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _check(rc, where):
+    if rc != abi.SRT_OK:
+        raise SrtError(rc, where)
+
+
+class DeviceScene:
+    """A flat scene resident on one HIP device (opaque srt_scene handle)."""
+
+    def __init__(self, flat: abi.FlatScene, device: int = 0):
+        self.L = load()
+        self.flat = flat
+        self.device = device
+        h = C.c_void_p()
+        d = flat.desc()
+        _check(self.L.srt_scene_create(device, C.byref(d), C.byref(h)), "srt_scene_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.srt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return int(self.L.srt_scene_device_bytes(self.h))
+
+    def rows(self, params):
+        return int(self.L.srt_rows_owned(C.byref(params)))
+
+    def render(self, params: abi.Params, want=("hit_id", "t", "rgb_linear", "rgb8")):
+        """srt_render: host buffers out.  Returns dict of numpy arrays + 'stats'."""
+        rows, W = self.rows(params), params.width
+        out = {}
+        if "hit_id" in want: out["hit_id"] = np.empty((rows, W), np.int32)
+        if "t" in want: out["t"] = np.empty((rows, W), np.float32)
+        if "rgb_linear" in want: out["rgb_linear"] = np.empty((rows, W, 3), np.float32)
+        if "rgb8" in want: out["rgb8"] = np.empty((rows, W, 3), np.uint8)
+        st = abi.Stats()
+        g = lambda k, ty: out[k].ctypes.data_as(ty) if k in out else ty()
+        _check(self.L.srt_render(self.h, C.byref(params), g("hit_id", _i32p), g("t", _f32p), g("rgb_linear", _f32p), g("rgb8", _u8p),
+                                 C.byref(st)), "srt_render")
+        out["stats"] = st.as_dict()
+        return out
+
+    def render_device(self, params: abi.Params, stream=0, hit_id=0, t=0, rgb_linear=0, rgb8=0):
+        """srt_render_device: raw device pointers (ints, e.g. torch.Tensor.data_ptr()) in, async on `stream`."""
+        _check(self.L.srt_render_device(self.h, C.byref(params), C.c_void_p(stream), C.c_void_p(hit_id), C.c_void_p(t),
+                                        C.c_void_p(rgb_linear), C.c_void_p(rgb8)), "srt_render_device")
+
+    def sync(self):
+        st = abi.Stats()
+        _check(self.L.srt_sync(self.h, C.byref(st)), "srt_sync")
+        return st.as_dict()

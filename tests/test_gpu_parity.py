@@ -1,0 +1,132 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+  * the golden vectors the compiled reference produced (tests/golden/), and
+  * the CPU oracle on the same inputs.
+Bars: hit ids and t bit-exact; pre-tone-map RGB within 1e-4 (north_star) -- in practice bit-exact up
+to the single powf in Phong's specular term; rgb8 exact except where a 1-ulp powf difference crosses
+an int(c*255) truncation boundary (<= 1 LSB, counted and bounded)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from simple_raytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+TOL_LINEAR = 1e-4          # BASELINE.json north_star: max per-pixel |dRGB| < 1e-4 before tone-mapping
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def srt():
+    from simple_raytracer_amd import lib
+    lib.load()
+    return lib
+
+
+_scene_cache = {}
+
+
+def device_scene(srt, name):
+    if name not in _scene_cache:
+        g = gu.GoldenScene(name)
+        _scene_cache[name] = (g, srt.DeviceScene(g.flat))
+    return _scene_cache[name]
+
+
+def check_rgb8(got, want, max_frac=2e-5):
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1, f"rgb8 differs by {diff.max()} LSB"
+    nbad = int((diff.max(-1) > 0).sum())
+    assert nbad <= max(1, int(max_frac * got.shape[0] * got.shape[1])), f"{nbad} pixels differ by 1 LSB"
+    return nbad
+
+
+@pytest.mark.parametrize("name,W,H,L", gu.all_renders())
+def test_gpu_matches_reference_goldens(srt, name, W, H, L):
+    g, ds = device_scene(srt, name)
+    o = ds.render(g.params(W, H, L))
+    assert np.array_equal(o["hit_id"], g.out(W, H, L, "hit_id")), "closest-hit ids differ from the reference"
+    assert gu.sha(o["t"]) == str(g.out(W, H, L, "sha_t")), "t differs from the reference (bitwise)"
+    check_rgb8(o["rgb8"], g.out(W, H, L, "rgb8"))
+    lin = g.out(W, H, L, "lin")
+    if lin is not None:
+        assert np.abs(o["rgb_linear"] - lin).max() < TOL_LINEAR
+    else:
+        st = int(g.out(W, H, L, "sub_stride"))
+        assert np.abs(o["rgb_linear"].reshape(-1, 3)[::st] - g.out(W, H, L, "sub_lin")).max() < TOL_LINEAR
+    st = o["stats"]
+    assert st["hit_rays"] == int((o["hit_id"] >= 0).sum()) and st["shadow_rays"] == st["hit_rays"] * L
+    assert st["primary_rays"] == W * H and st["rows"] == H
+
+
+@pytest.mark.parametrize("name,W,H,L", gu.all_renders(max_pixels=256 * 256))
+def test_gpu_matches_oracle_and_work_counts(srt, oracle, name, W, H, L):
+    g, ds = device_scene(srt, name)
+    p = g.params(W, H, L, flags=abi.SRT_FLAG_COUNT_WORK)
+    o = ds.render(p)
+    c = oracle.render(g.flat, p)
+    assert np.array_equal(o["hit_id"], c["hit_id"])
+    assert np.array_equal(bits(o["t"]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"])
+    # the counting build walks exactly the traversal the oracle mirrors (algorithmic-bytes model)
+    assert o["stats"]["node_tests"] == c["stats"]["node_tests"]
+    assert o["stats"]["tri_tests"] == c["stats"]["tri_tests"]
+    # and the counting build changes no result
+    o2 = ds.render(g.params(W, H, L))
+    assert np.array_equal(o2["hit_id"], o["hit_id"]) and np.array_equal(bits(o2["rgb_linear"]), bits(o["rgb_linear"]))
+    assert o2["stats"]["node_tests"] == 0
+
+
+def test_scanline_blocks_reassemble_bitwise(srt):
+    """Block-cyclic scanline tiling (the multi-GPU split) never changes a pixel."""
+    g, ds = device_scene(srt, "ground_bunny")
+    W, H, L = 192, 108, 1
+    whole = ds.render(g.params(W, H, L))
+    for world, rows in [(2, 8), (8, 16), (3, 5)]:
+        hit = np.full((H, W), -9, np.int32); rgb8 = np.zeros((H, W, 3), np.uint8)
+        lin = np.zeros((H, W, 3), np.float32); t = np.zeros((H, W), np.float32)
+        for rank in range(world):
+            o = ds.render(g.params(W, H, L, block_rows=rows, block_first=rank, block_stride=world))
+            ys = abi.rows_owned(H, rows, rank, world)
+            hit[ys] = o["hit_id"]; rgb8[ys] = o["rgb8"]; lin[ys] = o["rgb_linear"]; t[ys] = o["t"]
+        assert np.array_equal(hit, whole["hit_id"]) and np.array_equal(rgb8, whole["rgb8"])
+        assert np.array_equal(bits(lin), bits(whole["rgb_linear"])) and np.array_equal(bits(t), bits(whole["t"]))
+
+
+def test_soup_scene_matches_oracle(srt, oracle):
+    """Synthetic triangle soup (BASELINE config 5 generator) at a size the oracle finishes in seconds:
+    4 objects, cross-object shadows, built by the oracle-side reference-free path."""
+    import scenes
+    from tests_support import build_flat_scene
+    recipe, meshes = scenes.soup(20000)
+    flat = build_flat_scene(recipe, meshes)
+    ds = srt.DeviceScene(flat)
+    p = abi.make_params(512, 512, abi.light_staircase(recipe.light, 2), flags=abi.SRT_FLAG_COUNT_WORK)
+    o = ds.render(p); c = oracle.render(flat, p)
+    assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"])
+    assert o["stats"]["node_tests"] == c["stats"]["node_tests"] and o["stats"]["tri_tests"] == c["stats"]["tri_tests"]
+    assert (o["hit_id"] >= 0).sum() > 1000
+
+
+def test_bad_scene_is_rejected_not_faulted(srt):
+    g, _ = device_scene(srt, "cube")
+    import copy
+    f = copy.deepcopy(g.flat)
+    f.node_left = f.node_left.copy(); f.node_left[0] = 77          # child out of range
+    with pytest.raises(srt.SrtError) as e:
+        srt.DeviceScene(f)
+    assert e.value.code == 2
+    f = copy.deepcopy(g.flat)
+    f.node_first = f.node_first.copy(); f.node_first[2] = 0        # leaves not contiguous in visit order
+    with pytest.raises(srt.SrtError):
+        srt.DeviceScene(f)
+    p = g.params(64, 64, 1); p.spp = 4
+    _, ds = device_scene(srt, "cube")
+    with pytest.raises(srt.SrtError):
+        ds.render(p)
