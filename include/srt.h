@@ -103,15 +103,21 @@ typedef struct srt_params {
 } srt_params;
 
 typedef struct srt_stats {
-    uint64_t primary_rays;         /* width x owned rows x spp                                      */
+    uint64_t primary_rays;         /* width x owned rows x spp (of the last render)                 */
     uint64_t hit_rays;             /* primary rays that hit                                         */
     uint64_t shadow_rays;          /* hit_rays x n_lights (algorithmic count)         */
-    uint64_t node_tests;           /* slab tests executed (SRT_FLAG_COUNT_WORK only, else 0)        */
-    uint64_t tri_tests;            /* Moller-Trumbore tests executed (idem)                         */
-    float    ms_primary;           /* HIP-event time of the closest-hit kernel                      */
-    float    ms_shade;             /* HIP-event time of the shadow + shading kernel                 */
+    /* work of the kernels' own traversal; SRT_FLAG_COUNT_WORK only, else 0 */
+    uint64_t node_tests_primary;   /* slab tests in the closest-hit kernel                          */
+    uint64_t tri_tests_primary;    /* Moller-Trumbore tests in the closest-hit kernel               */
+    uint64_t node_tests_shadow;    /* slab tests in the shadow/shade kernel                         */
+    uint64_t tri_tests_shadow;     /* Moller-Trumbore tests in the shadow/shade kernel              */
+    /* HIP-event times on the launch stream, AVERAGED over the `launches` renders since the previous
+     * srt_sync (at most 64 are kept; older ones are dropped from the average) */
+    float    ms_primary;           /* closest-hit kernel                                            */
+    float    ms_shade;             /* shadow + shading kernel                                       */
     float    ms_total;             /* first launch -> last kernel done                              */
-    uint32_t rows;                 /* rows written by this call                                     */
+    uint32_t launches;
+    uint32_t rows;                 /* rows written by the last render                               */
 } srt_stats;
 
 typedef struct srt_scene srt_scene;     /* opaque: device-resident flat scene + workspace           */

@@ -175,7 +175,7 @@ typedef struct {
     v3* normal;         /* n_tris */
 } scene_view;
 
-typedef struct { uint64_t node_tests, tri_tests; } work_ctr;
+typedef struct { uint64_t node_tests, tri_tests; } work_ctr;   /* one per kernel: primary, shadow */
 
 /* a3: boundingBoxIntersection :296-317 fused with the closest-hit loop of rayIntersection :424-431.
  * DFS left-first; every leaf whose ancestors all pass the slab test contributes its triangles in
@@ -251,16 +251,16 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
         for (uint32_t b = p->block_first; b < nblocks; b += p->block_stride)
             for (uint32_t y = b * p->block_rows; y < (b + 1) * p->block_rows && y < H; y++) row_y[r++] = y;
     }
-    uint64_t hits = 0, node_tests = 0, tri_tests = 0;
+    uint64_t hits = 0, node_tests = 0, tri_tests = 0, snode_tests = 0, stri_tests = 0;
     /* sendRaysAndIntersectPointsColors:511-517: i = px + int(-W/2), dir = (i, j, focal), origin 0 */
     const int i0 = (int)(-(float)W / 2), j0 = (int)(-(float)H / 2);
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, node_tests, tri_tests)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, node_tests, tri_tests, snode_tests, stri_tests)
 #endif
     for (uint32_t r = 0; r < rows; r++) {
         const uint32_t y = row_y[r];
-        work_ctr w = { 0, 0 };
+        work_ctr w = { 0, 0 }, ws = { 0, 0 };
         for (uint32_t x = 0; x < W; x++) {
             const size_t pix = (size_t)r * W + x;
             v3 o = v3make(0.0f, 0.0f, 0.0f);
@@ -290,7 +290,7 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                 const float ka = d->obj_material[obj * 3], ks = d->obj_material[obj * 3 + 1], sh = d->obj_material[obj * 3 + 2];
                 for (uint32_t l = 0; l < p->n_lights; l++) {                    /* softShadow:366-383 */
                     v3 L = v3make(p->light_pos[l * 3], p->light_pos[l * 3 + 1], p->light_pos[l * 3 + 2]);
-                    int sh_hit = in_shadow(&s, obj, L, best, dir, &w);
+                    int sh_hit = in_shadow(&s, obj, L, best, dir, &ws);
                     v3 c = phong(s.normal[best_id], o, dir, L, color, ka, ks, sh, best);
                     if (sh_hit) c = v3make(c.x / p->shadow_div, c.y / p->shadow_div, c.z / p->shadow_div);   /* :369 */
                     sum = v3add(sum, c);                                         /* :370 */
@@ -307,14 +307,17 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
             }
         }
         node_tests += w.node_tests; tri_tests += w.tri_tests;
+        snode_tests += ws.node_tests; stri_tests += ws.tri_tests;
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->primary_rays = (uint64_t)W * rows;
         stats->hit_rays = hits;
         stats->shadow_rays = hits * p->n_lights;
-        stats->node_tests = node_tests;
-        stats->tri_tests = tri_tests;
+        stats->node_tests_primary = node_tests;
+        stats->tri_tests_primary = tri_tests;
+        stats->node_tests_shadow = snode_tests;
+        stats->tri_tests_shadow = stri_tests;
         stats->rows = rows;
     }
     free(row_y); free(s.geom); free(s.normal);

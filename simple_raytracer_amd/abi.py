@@ -48,13 +48,17 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("primary_rays", C.c_uint64), ("hit_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
-        ("node_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+        ("node_tests_primary", C.c_uint64), ("tri_tests_primary", C.c_uint64),
+        ("node_tests_shadow", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
         ("ms_primary", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
-        ("rows", C.c_uint32),
+        ("launches", C.c_uint32), ("rows", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["node_tests"] = d["node_tests_primary"] + d["node_tests_shadow"]
+        d["tri_tests"] = d["tri_tests_primary"] + d["tri_tests_shadow"]
+        return d
 
 
 def _ptr(a, ty):

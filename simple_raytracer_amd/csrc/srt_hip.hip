@@ -49,7 +49,7 @@ struct DevParams {
     uint32_t bg;                  // r | g << 8 | b << 16
 };
 
-// counters[0] hit pixels, [1] node tests, [2] triangle tests
+// counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
 __device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
         }
     }
     wave_add(counters + 0, is_hit ? 1ull : 0ull);
-    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+    if (COUNT) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
 }
 
 // =================================================================================================
@@ -234,6 +234,9 @@ static thread_local int g_last_hip = 0;
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return SRT_ERR_DEVICE; } \
     } while (0)
 
+constexpr int NCTR = 8;          // device work counters
+constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
+
 struct srt_scene {
     int device = 0;
     DevScene dev{};
@@ -244,7 +247,9 @@ struct srt_scene {
     float* ws_lin = nullptr; uint8_t* ws_rgb8 = nullptr; size_t ws_out_pixels = 0;
     float* d_lights = nullptr; float* h_lights = nullptr; uint32_t lights_cap = 0, lights_valid = 0;
     unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;
-    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t ev[RING][3] = {};
+    uint32_t ring_count = 0;         // renders since the last srt_sync
+    hipEvent_t last_done = nullptr;  // ev[..][2] of the most recent render
     hipStream_t last_stream = nullptr;
     bool pending = false;
     srt_stats last{};
@@ -336,7 +341,7 @@ uint32_t srt_rows_owned(const srt_params* p) {
 int srt_scene_destroy(srt_scene* s) {
     if (!s) return SRT_ERR_ARG;
     (void)hipSetDevice(s->device);
-    if (s->pending) (void)hipEventSynchronize(s->ev[2]);
+    if (s->pending) (void)hipEventSynchronize(s->last_done);
     for (void* d : s->allocs) (void)hipFree(d);
     if (s->ws_hit) (void)hipFree(s->ws_hit);
     if (s->ws_t) (void)hipFree(s->ws_t);
@@ -346,7 +351,7 @@ int srt_scene_destroy(srt_scene* s) {
     if (s->h_lights) (void)hipHostFree(s->h_lights);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
-    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& tr : s->ev) for (auto& e : tr) if (e) (void)hipEventDestroy(e);
     delete s;
     return SRT_OK;
 }
@@ -460,9 +465,9 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     }
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
-    hipError_t e = hipMalloc((void**)&s->d_counters, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault);
-    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+    hipError_t e = hipMalloc((void**)&s->d_counters, NCTR * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
+    for (int i = 0; i < RING * 3 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i / 3][i % 3]);
     if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
     *out = s;
     return SRT_OK;
@@ -494,7 +499,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     const size_t pixels = (size_t)p->width * rows;
     // workspace for hit ids / t when the caller does not want them (the shade kernel does)
     if ((!d_hit_id || !d_t) && s->ws_pixels < pixels) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
         if (s->ws_hit) (void)hipFree(s->ws_hit);
         if (s->ws_t) (void)hipFree(s->ws_t);
         s->ws_hit = nullptr; s->ws_t = nullptr; s->ws_pixels = 0;
@@ -505,7 +510,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     if (!d_hit_id) d_hit_id = s->ws_hit;
     if (!d_t) d_t = s->ws_t;
     if (p->n_lights > s->lights_cap) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
         if (s->d_lights) (void)hipFree(s->d_lights);
         if (s->h_lights) (void)hipHostFree(s->h_lights);
         s->d_lights = nullptr; s->h_lights = nullptr; s->lights_cap = 0;
@@ -515,12 +520,12 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     }
     const size_t light_bytes = (size_t)p->n_lights * 3 * sizeof(float);
     if (p->n_lights && !(s->lights_valid == p->n_lights && std::memcmp(s->h_lights, p->light_pos, light_bytes) == 0)) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));     // staging buffer still in flight
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));     // staging buffer still in flight
         std::memcpy(s->h_lights, p->light_pos, light_bytes);
         HIP_TRY(hipMemcpyAsync(s->d_lights, s->h_lights, light_bytes, hipMemcpyHostToDevice, stream));
         s->lights_valid = p->n_lights;
     }
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, NCTR * sizeof(unsigned long long), stream));
 
     DevParams dp;
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
@@ -532,16 +537,19 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
 
     const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
-    HIP_TRY(hipEventRecord(s->ev[0], stream));
+    hipEvent_t* ev = s->ev[s->ring_count % RING];
+    HIP_TRY(hipEventRecord(ev[0], stream));
     if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
     else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev[1], stream));
+    HIP_TRY(hipEventRecord(ev[1], stream));
     if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
     else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev[2], stream));
-    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    s->last_done = ev[2];
+    s->ring_count++;
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     s->last_stream = stream;
     s->pending = true;
     s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
@@ -553,15 +561,25 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
     if (s->pending) {
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
-        float a = 0.f, b = 0.f, c = 0.f;
-        HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&c, s->ev[0], s->ev[2]));
-        s->last.ms_primary = a; s->last.ms_shade = b; s->last.ms_total = c;
+        const uint32_t n = s->ring_count < RING ? s->ring_count : RING;
+        double a = 0., b = 0., c = 0.;
+        for (uint32_t k = 0; k < n; k++) {
+            hipEvent_t* ev = s->ev[(s->ring_count - 1 - k) % RING];
+            float x = 0.f, y = 0.f, z = 0.f;
+            HIP_TRY(hipEventElapsedTime(&x, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&y, ev[1], ev[2]));
+            HIP_TRY(hipEventElapsedTime(&z, ev[0], ev[2]));
+            a += x; b += y; c += z;
+        }
+        s->last.ms_primary = (float)(a / n); s->last.ms_shade = (float)(b / n); s->last.ms_total = (float)(c / n);
+        s->last.launches = n;
+        s->ring_count = 0;
         s->last.hit_rays = s->h_counters[0];
         s->last.shadow_rays = s->last.shadow_rays * s->h_counters[0];
-        s->last.node_tests = s->h_counters[1];
-        s->last.tri_tests = s->h_counters[2];
+        s->last.node_tests_primary = s->h_counters[1];
+        s->last.tri_tests_primary = s->h_counters[2];
+        s->last.node_tests_shadow = s->h_counters[3];
+        s->last.tri_tests_shadow = s->h_counters[4];
         s->pending = false;
     }
     if (stats) *stats = s->last;
@@ -576,7 +594,7 @@ int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, flo
     const uint32_t rows = srt_rows_owned(p);
     const size_t pixels = (size_t)p->width * rows;
     if (pixels > s->ws_out_pixels) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->ev[2]));
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
         if (s->ws_lin) (void)hipFree(s->ws_lin);
         if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
         s->ws_lin = nullptr; s->ws_rgb8 = nullptr; s->ws_out_pixels = 0;
