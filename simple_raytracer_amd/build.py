@@ -48,8 +48,32 @@ def build_hip(force=False, verbose=False):
     return LIB_HIP
 
 
+LIB_HOST = os.path.join(HERE, "libsrt_host.so")
+HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+
+
+def build_host(force=False, verbose=False):
+    """Host-side C++ mirror of the reference's scene interface (g++); links the HIP library for the
+    drop-in sendRaysAndIntersectPointsColors."""
+    hdir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(hdir, "srt_host.cpp"), os.path.join(hdir, "srt_host_c.cpp")]
+    deps = srcs + [os.path.join(hdir, "srt_host.h"), os.path.join(HERE, "..", "include", "srt.h"), LIB_HIP]
+    if not force and not _stale(LIB_HOST, deps):
+        return LIB_HOST
+    cmd = ["g++"] + HOST_FLAGS + ["-o", LIB_HOST] + srcs + ["-L" + HERE, "-lsrt_hip", "-Wl,-rpath,$ORIGIN", "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed for libsrt_host.so")
+    if verbose and r.stderr:
+        print(r.stderr)
+    return LIB_HOST
+
+
 def build_all(force=False, verbose=False):
-    return [build_hip(force, verbose)]
+    return [build_hip(force, verbose), build_host(force, verbose)]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,608 @@
+// srt_host.cpp -- host-side mirror of the reference's scene interface (see srt_host.h).
+//
+// Everything here runs once per frame on the host, as in the reference: transforms (Object.cpp:183-190),
+// the median-split hierarchy builder (Object.cpp:205-284), the flattener that writes the flat scene of
+// include/srt.h, and the drop-in sendRaysAndIntersectPointsColors that calls the HIP path through the
+// C ABI.  Built with -ffp-contract=off: transformed points, boxes and the builder's comparisons must be
+// bit-identical to what the reference computes, because leaf order decides tie-breaks.
+#include "srt_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+#include <zlib.h>
+
+namespace srt_host {
+
+// ------------------------------------------------------------------------------------------------
+// glm operations the reference's host code applies (exact op order)
+// ------------------------------------------------------------------------------------------------
+vec4 operator*(const mat4& m, const vec4& v) {
+    // type_mat4x4.inl:562-573: Add0 = m0*v0 + m1*v1; Add1 = m2*v2 + m3*v3; Add0 + Add1
+    vec4 r;
+    for (int i = 0; i < 4; i++) r[i] = (m[0][i] * v[0] + m[1][i] * v[1]) + (m[2][i] * v[2] + m[3][i] * v[3]);
+    return r;
+}
+
+mat4 operator*(const mat4& a, const mat4& b) {
+    // type_mat4x4.inl:681-700 (unaligned path): tmp = A0*b.x; tmp += A1*b.y; tmp += A2*b.z; tmp += A3*b.w
+    mat4 r;
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            float t = a[0][i] * b[j][0];
+            t += a[1][i] * b[j][1];
+            t += a[2][i] * b[j][2];
+            t += a[3][i] * b[j][3];
+            r[j][i] = t;
+        }
+    return r;
+}
+
+float radians(float degrees) { return degrees * static_cast<float>(0.01745329251994329576923690768489); }
+
+mat4 inverse(const mat4& m) {
+    // func_matrix.inl:388-446
+    float Coef00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+    float Coef02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+    float Coef03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    float Coef04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    float Coef06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float Coef07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    float Coef08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+    float Coef10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+    float Coef11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    float Coef12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    float Coef14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+    float Coef15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    float Coef16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+    float Coef18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+    float Coef19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    float Coef20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    float Coef22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+    float Coef23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    vec4 Fac0(Coef00, Coef00, Coef02, Coef03), Fac1(Coef04, Coef04, Coef06, Coef07), Fac2(Coef08, Coef08, Coef10, Coef11);
+    vec4 Fac3(Coef12, Coef12, Coef14, Coef15), Fac4(Coef16, Coef16, Coef18, Coef19), Fac5(Coef20, Coef20, Coef22, Coef23);
+    vec4 Vec0(m[1][0], m[0][0], m[0][0], m[0][0]), Vec1(m[1][1], m[0][1], m[0][1], m[0][1]);
+    vec4 Vec2(m[1][2], m[0][2], m[0][2], m[0][2]), Vec3(m[1][3], m[0][3], m[0][3], m[0][3]);
+    const float SignA[4] = { +1, -1, +1, -1 }, SignB[4] = { -1, +1, -1, +1 };
+    mat4 Inverse;
+    for (int i = 0; i < 4; i++) {
+        float Inv0 = (Vec1[i] * Fac0[i] - Vec2[i] * Fac1[i]) + Vec3[i] * Fac2[i];
+        float Inv1 = (Vec0[i] * Fac0[i] - Vec2[i] * Fac3[i]) + Vec3[i] * Fac4[i];
+        float Inv2 = (Vec0[i] * Fac1[i] - Vec1[i] * Fac3[i]) + Vec3[i] * Fac5[i];
+        float Inv3 = (Vec0[i] * Fac2[i] - Vec1[i] * Fac4[i]) + Vec2[i] * Fac5[i];
+        Inverse[0][i] = Inv0 * SignA[i]; Inverse[1][i] = Inv1 * SignB[i];
+        Inverse[2][i] = Inv2 * SignA[i]; Inverse[3][i] = Inv3 * SignB[i];
+    }
+    vec4 Row0(Inverse[0][0], Inverse[1][0], Inverse[2][0], Inverse[3][0]);
+    vec4 Dot0(m[0][0] * Row0[0], m[0][1] * Row0[1], m[0][2] * Row0[2], m[0][3] * Row0[3]);
+    float Dot1 = (Dot0.x + Dot0.y) + (Dot0.z + Dot0.w);
+    float OneOverDeterminant = 1.0f / Dot1;
+    for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) Inverse[j][i] = Inverse[j][i] * OneOverDeterminant;
+    return Inverse;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Transformation.cpp:6-90
+// ------------------------------------------------------------------------------------------------
+mat4 Transformation::scaleObj(float sx, float sy, float sz) {
+    mat4 m(0.0f); m[0][0] = sx; m[1][1] = sy; m[2][2] = sz; m[3][3] = 1.0f; return m;
+}
+mat4 Transformation::rotateObjX(float degree) {
+    mat4 m(0.0f);
+    m[0][0] = 1; m[1][1] = std::cos(degree); m[1][2] = -std::sin(degree);
+    m[2][1] = std::sin(degree); m[2][2] = std::cos(degree); m[3][3] = 1.0f;
+    return m;
+}
+mat4 Transformation::rotateObjY(float degree) {
+    mat4 m(0.0f);
+    m[0][0] = std::cos(degree); m[0][2] = std::sin(degree); m[1][1] = 1.0f;
+    m[2][0] = -std::sin(degree); m[2][2] = std::cos(degree); m[3][3] = 1.0f;
+    return m;
+}
+mat4 Transformation::rotateObjZ(float degree) {
+    mat4 m(0.0f);
+    m[0][0] = std::cos(degree); m[0][1] = -std::sin(degree);
+    m[1][0] = std::sin(degree); m[1][1] = std::cos(degree); m[2][2] = 1.0f; m[3][3] = 1.0f;
+    return m;
+}
+mat4 Transformation::mirrorObj(bool mirrorX, bool mirrorY, bool mirrorZ) {
+    mat4 m(1.0f);
+    if (mirrorX) m[0][0] = -1.0f;
+    if (mirrorY) m[1][1] = -1.0f;
+    if (mirrorZ) m[2][2] = -1.0f;
+    return m;
+}
+mat4 Transformation::shearObj(float shearXY, float shearXZ, float shearYX, float shearYZ, float shearZX, float shearZY) {
+    mat4 m(1.0f);
+    m[1][0] = shearXY; m[2][0] = shearXZ; m[0][1] = shearYX; m[2][1] = shearYZ; m[0][2] = shearZX; m[1][2] = shearZY;
+    return m;
+}
+mat4 Transformation::changeObjPosition(vec3 position) {
+    mat4 m(1.0f); m[3] = vec4(position, 1.0f); return m;
+}
+mat4 Transformation::createViewMatrix(vec3 position, vec3 rotation) {
+    mat4 m = changeObjPosition(position);
+    m = m * rotateObjZ(rotation.z);
+    m = m * rotateObjY(rotation.y);
+    m = m * rotateObjX(rotation.x);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Texture decoding for the loader (the reference uses stbi_load(path, ..., 3), Object.cpp:57).
+// Supported here: PNG (8/16-bit, grey / RGB / palette / alpha, non-interlaced), binary PPM, 24/32-bit
+// BMP.  Anything else (JPEG) fails to load, which the reference also tolerates (:63-65).
+// ------------------------------------------------------------------------------------------------
+static bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+static uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+static bool decode_png(const std::vector<unsigned char>& d, Texture& t) {
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    if (d.size() < 33 || std::memcmp(d.data(), sig, 8) != 0) return false;
+    uint32_t W = 0, H = 0; int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    size_t pos = 8;
+    while (pos + 12 <= d.size()) {
+        uint32_t len = be32(&d[pos]); const unsigned char* ty = &d[pos + 4];
+        if (pos + 12 + (size_t)len > d.size()) return false;
+        const unsigned char* body = &d[pos + 8];
+        if (!std::memcmp(ty, "IHDR", 4)) { W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        else if (!std::memcmp(ty, "PLTE", 4)) plte.assign(body, body + len);
+        else if (!std::memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(ty, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    if (!W || !H || interlace || (depth != 8 && depth != 16 && ctype != 3)) return false;
+    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || (ctype == 3 && depth != 8)) return false;
+    const size_t bpp = (size_t)ch * depth / 8, stride = (size_t)W * bpp;
+    std::vector<unsigned char> raw((stride + 1) * H);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<unsigned char> img(stride * H);
+    for (uint32_t y = 0; y < H; y++) {
+        const unsigned char* in = &raw[(stride + 1) * y]; unsigned char* out = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        const int ft = in[0]; in++;
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? out[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, x = in[i];
+            switch (ft) {
+            case 0: break;
+            case 1: x += a; break;
+            case 2: x += b; break;
+            case 3: x += (a + b) >> 1; break;
+            case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                      x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+            default: return false;
+            }
+            out[i] = (unsigned char)x;
+        }
+    }
+    t.dim.x = (int)W; t.dim.y = (int)H; t.rgb.resize((size_t)W * H * 3);
+    const size_t step = depth / 8;      // 16-bit samples: keep the high byte (stb_image does the same)
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        const unsigned char* px = &img[i * bpp]; unsigned char* o = &t.rgb[i * 3];
+        if (ctype == 3) { size_t k = (size_t)px[0] * 3; if (k + 2 >= plte.size()) return false; o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2]; }
+        else if (ch <= 2) { o[0] = o[1] = o[2] = px[0]; }
+        else { o[0] = px[0]; o[1] = px[step]; o[2] = px[2 * step]; }
+    }
+    return true;
+}
+
+static bool decode_ppm(const std::vector<unsigned char>& d, Texture& t) {
+    if (d.size() < 11 || d[0] != 'P' || d[1] != '6') return false;
+    size_t pos = 2; int vals[3], n = 0;
+    while (n < 3 && pos < d.size()) {
+        while (pos < d.size() && (std::isspace(d[pos]) || d[pos] == '#')) { if (d[pos] == '#') while (pos < d.size() && d[pos] != '\n') pos++; else pos++; }
+        int v = 0; bool any = false;
+        while (pos < d.size() && std::isdigit(d[pos])) { v = v * 10 + (d[pos] - '0'); pos++; any = true; }
+        if (!any) return false;
+        vals[n++] = v;
+    }
+    pos++;
+    if (n < 3 || vals[2] != 255 || pos + (size_t)vals[0] * vals[1] * 3 > d.size()) return false;
+    t.dim.x = vals[0]; t.dim.y = vals[1]; t.rgb.assign(d.begin() + pos, d.begin() + pos + (size_t)vals[0] * vals[1] * 3);
+    return true;
+}
+
+static bool decode_bmp(const std::vector<unsigned char>& d, Texture& t) {
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    auto le32 = [&](size_t o) { return (int32_t)((uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24)); };
+    const int32_t off = le32(10), W = le32(18), Hs = le32(22); const int bpp = d[28] | (d[29] << 8), comp = le32(30);
+    if (W <= 0 || Hs == 0 || (bpp != 24 && bpp != 32) || comp != 0) return false;
+    const int32_t H = std::abs(Hs); const size_t stride = (((size_t)W * bpp / 8) + 3) & ~(size_t)3;
+    if ((size_t)off + stride * H > d.size()) return false;
+    t.dim.x = W; t.dim.y = H; t.rgb.resize((size_t)W * H * 3);
+    for (int32_t y = 0; y < H; y++) {
+        const unsigned char* row = &d[off + stride * (Hs > 0 ? (H - 1 - y) : y)];
+        for (int32_t x = 0; x < W; x++) { const unsigned char* p = row + (size_t)x * bpp / 8; unsigned char* o = &t.rgb[((size_t)y * W + x) * 3]; o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
+    }
+    return true;
+}
+
+static bool load_texture(const std::string& path, Texture& t) {
+    std::vector<unsigned char> d;
+    if (!read_file(path, d)) return false;
+    return decode_png(d, t) || decode_ppm(d, t) || decode_bmp(d, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// loadObjFile, Object.cpp:25-170.  OBJ / MTL parsing restates what tinyobjloader's ObjReader does for
+// the statements the reference's assets use (v, vt, vn, f, usemtl, mtllib; newmtl, map_Kd):
+// triangulation on (quads split along the shorter diagonal, tiny_obj_loader.h:1562-1605; larger
+// polygons as a fan -- tinyobj uses earcut there), faces in file order.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ObjIndex { int v = -1, vt = -1, vn = -1; };
+struct ObjFace { ObjIndex i[3]; int material = -1; };
+
+bool fix_index(int idx, int n, int& out) {          // tinyobj fixIndex: 1-based, negative = relative
+    if (idx > 0) { out = idx - 1; return true; }
+    if (idx < 0) { out = n + idx; return out >= 0; }
+    return false;
+}
+
+bool parse_triple(const char*& p, int nv, int nvt, int nvn, ObjIndex& o) {
+    char* e = nullptr;
+    long a = std::strtol(p, &e, 10);
+    if (e == p || !fix_index((int)a, nv, o.v)) return false;
+    p = e;
+    if (*p != '/') return true;
+    p++;
+    if (*p == '/') { p++; long c = std::strtol(p, &e, 10); if (e != p) { fix_index((int)c, nvn, o.vn); p = e; } return true; }
+    long b = std::strtol(p, &e, 10);
+    if (e != p) { fix_index((int)b, nvt, o.vt); p = e; }
+    if (*p == '/') { p++; long c = std::strtol(p, &e, 10); if (e != p) { fix_index((int)c, nvn, o.vn); p = e; } }
+    return true;
+}
+
+std::string dirname_of(const std::string& path) {
+    size_t k = path.find_last_of("/\\");
+    return k == std::string::npos ? std::string() : path.substr(0, k + 1);
+}
+std::string trim(const std::string& s) {
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+} // namespace
+
+void ObjectManager::loadObjFile(const std::string& objFilename) {
+    objColors[objFilename] = vec3(1.f, 0.f, 0.f);                        // :29
+    objProperties[objFilename] = vec3(0.2f, 0.5f, 15.0f);                // :31-34
+    std::vector<float> V, VT, VN;
+    std::vector<ObjFace> faces;
+    std::vector<std::string> mat_names, mat_tex;
+    std::ifstream in(objFilename);
+    if (!in) {
+        std::cerr << "TinyObjReader: Cannot open file [" << objFilename << "]\n";      // :35-39 prints and carries on
+        objTriangles[objFilename] = {};
+        return;
+    }
+    int cur_mat = -1;
+    std::string line;
+    while (std::getline(in, line)) {
+        const char* p = line.c_str();
+        while (*p == ' ' || *p == '\t') p++;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            char* e; float x = std::strtof(p + 2, &e), y = std::strtof(e, &e), z = std::strtof(e, &e);
+            V.push_back(x); V.push_back(y); V.push_back(z);
+        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
+            char* e; float u = std::strtof(p + 3, &e), v = std::strtof(e, &e);
+            VT.push_back(u); VT.push_back(v);
+        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+            char* e; float x = std::strtof(p + 3, &e), y = std::strtof(e, &e), z = std::strtof(e, &e);
+            VN.push_back(x); VN.push_back(y); VN.push_back(z);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            p += 2;
+            std::vector<ObjIndex> poly;
+            const int nv = (int)V.size() / 3, nvt = (int)VT.size() / 2, nvn = (int)VN.size() / 3;
+            while (true) {
+                while (*p == ' ' || *p == '\t') p++;
+                if (!*p || *p == '\r' || *p == '\n' || *p == '#') break;
+                ObjIndex o;
+                if (!parse_triple(p, nv, nvt, nvn, o)) break;
+                poly.push_back(o);
+            }
+            auto emit = [&](int a, int b, int c) { ObjFace f; f.i[0] = poly[a]; f.i[1] = poly[b]; f.i[2] = poly[c]; f.material = cur_mat; faces.push_back(f); };
+            if (poly.size() == 3) emit(0, 1, 2);
+            else if (poly.size() == 4) {
+                bool ok = true;
+                for (auto& q : poly) ok &= (q.v >= 0 && 3 * (size_t)q.v + 2 < V.size());
+                if (!ok) continue;
+                const float* v0 = &V[3 * poly[0].v], *v1 = &V[3 * poly[1].v], *v2 = &V[3 * poly[2].v], *v3 = &V[3 * poly[3].v];
+                float e02x = v2[0] - v0[0], e02y = v2[1] - v0[1], e02z = v2[2] - v0[2];
+                float e13x = v3[0] - v1[0], e13y = v3[1] - v1[1], e13z = v3[2] - v1[2];
+                float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z, sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+                if (sqr02 < sqr13) { emit(0, 1, 2); emit(0, 2, 3); } else { emit(0, 1, 3); emit(1, 2, 3); }
+            } else if (poly.size() > 4) {
+                for (size_t k = 1; k + 1 < poly.size(); k++) emit(0, (int)k, (int)k + 1);
+            }
+        } else if (!std::strncmp(p, "usemtl", 6)) {
+            std::string name = trim(p + 6);
+            cur_mat = -1;
+            for (size_t k = 0; k < mat_names.size(); k++) if (mat_names[k] == name) cur_mat = (int)k;
+        } else if (!std::strncmp(p, "mtllib", 6)) {
+            std::string mtl = dirname_of(objFilename) + trim(p + 6);
+            std::ifstream mf(mtl);
+            std::string ml;
+            while (mf && std::getline(mf, ml)) {
+                std::string s = trim(ml);
+                if (!s.compare(0, 6, "newmtl")) { mat_names.push_back(trim(s.substr(6))); mat_tex.emplace_back(); }
+                else if (!s.compare(0, 6, "map_Kd") && !mat_names.empty()) {
+                    std::istringstream ss(s.substr(6)); std::string tok, last;
+                    while (ss >> tok) last = tok;          // options (-s, -o ...) precede the file name
+                    mat_tex.back() = last;
+                }
+            }
+        }
+    }
+
+    for (const std::string& texturePath : mat_tex) {                      // :52-68
+        if (texturePath.empty() || textureData.count(texturePath)) continue;
+        Texture t;
+        if (load_texture(texturePath, t)) textureData[texturePath] = std::move(t);
+        else std::cerr << "Failed to load texture: " << texturePath << std::endl;
+    }
+
+    std::vector<Triangle> triangles;
+    triangles.reserve(faces.size());
+    for (const ObjFace& f : faces) {                                      // :70-167
+        Triangle tria;
+        for (int v = 0; v < 3; v++) {
+            std::string texturePath;
+            vec2 texCoordinate(0, 0);
+            vec4 vertex(0.0f, 0.0f, 0.0f, 1.0f);
+            vec3 vnormal(0.0f, 0.0f, 0.0f), vcolor(1.0f, 1.0f, 1.0f);
+            const ObjIndex& idx = f.i[v];
+            if (idx.v >= 0 && 3 * (size_t)idx.v + 2 < V.size()) { vertex.x = V[3 * idx.v]; vertex.y = V[3 * idx.v + 1]; vertex.z = V[3 * idx.v + 2]; }
+            if (idx.vn >= 0 && 3 * (size_t)idx.vn + 2 < VN.size()) { vnormal = vec3(VN[3 * idx.vn], VN[3 * idx.vn + 1], VN[3 * idx.vn + 2]); }
+            if (idx.vt >= 0 && 2 * (size_t)idx.vt + 1 < VT.size()) {
+                const float tx = VT[2 * idx.vt], ty = VT[2 * idx.vt + 1];
+                if (f.material >= 0 && f.material < (int)mat_names.size()) {
+                    texturePath = mat_tex[f.material];
+                    auto it = texturePath.empty() ? textureData.end() : textureData.find(texturePath);
+                    if (it != textureData.end() && it->second.dim.x > 0 && it->second.dim.y > 0) {
+                        const ivec2 texDim = it->second.dim;
+                        int u = static_cast<int>(std::floor(tx * texDim.x)) % texDim.x;              // :113
+                        int w = static_cast<int>(std::floor((1.0f - ty) * texDim.y)) % texDim.y;     // :114
+                        u = (u + texDim.x) % texDim.x; w = (w + texDim.y) % texDim.y;                // :116-117
+                        texCoordinate = vec2((float)u, (float)w);
+                        const size_t texIndex = ((size_t)w * texDim.x + u) * 3;
+                        vcolor = vec3(it->second.rgb[texIndex] / 255.0f, it->second.rgb[texIndex + 1] / 255.0f, it->second.rgb[texIndex + 2] / 255.0f);
+                    }
+                }
+            }
+            if (v == 0) { tria.pointOne = vertex; tria.normalOne = vnormal; tria.colorOneCoordinate = texCoordinate; tria.color = vcolor; tria.textureName = texturePath; }
+            if (v == 1) { tria.pointTwo = vertex; tria.normalTwo = vnormal; tria.colorTwoCoordinate = texCoordinate; }
+            if (v == 2) { tria.pointThree = vertex; tria.normalThree = vnormal; tria.colorThreeCoordinate = texCoordinate; }
+        }
+        triangles.push_back(tria);
+    }
+    objTriangles[objFilename] = triangles;
+}
+
+const std::vector<Triangle>& ObjectManager::getTriangles(const std::string& objFilename) const { return objTriangles.at(objFilename); }
+void ObjectManager::setTriangles(const std::string& objFilename, const std::vector<Triangle>& triangles) { objTriangles[objFilename] = triangles; }
+void ObjectManager::setColor(const std::string& objFilename, const vec3& color) { objColors[objFilename] = color; }
+vec3 ObjectManager::getColor(const std::string& objFilename) const { return objColors.at(objFilename); }
+
+void ObjectManager::transformTriangles(const std::string& objFilename, const mat4& matrix) {
+    std::vector<Triangle>& triangles = objTriangles[objFilename];      // operator[]: creates an empty object, like the reference
+    for (Triangle& t : triangles) {
+        t.pointOne = matrix * t.pointOne;
+        t.pointTwo = matrix * t.pointTwo;
+        t.pointThree = matrix * t.pointThree;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// createBoundingHierarchy, Object.cpp:205-284.  Same tree, same leaf order as the reference builds:
+// std::sort (libstdc++ introsort) over the node's triangles with the reference's three comparators;
+// the permutation std::sort produces depends only on the comparison outcomes, so sorting indices with
+// the same keys gives the reference's order without copying 152-byte Triangles around.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Builder {
+    const std::vector<Triangle>& tris;
+    ObjectManager::Hierarchy& h;
+
+    void bounds(uint32_t first, uint32_t count, vec3& mn, vec3& mx) const {       // calculateBoundingBoxes :205-221
+        mn = vec3(FLT_MAX, FLT_MAX, FLT_MAX); mx = vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+        for (uint32_t k = 0; k < count; k++) {
+            const Triangle& t = tris[h.order[first + k]];
+            const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
+            for (int j = 0; j < 3; j++) for (int a = 0; a < 3; a++) { float v = (*p[j])[a]; if (v < mn[a]) mn[a] = v; }   // glm::min(x,y) = y<x ? y : x
+            for (int j = 0; j < 3; j++) for (int a = 0; a < 3; a++) { float v = (*p[j])[a]; if (mx[a] < v) mx[a] = v; }   // glm::max(x,y) = x<y ? y : x
+        }
+    }
+
+    void split(int32_t node) {                                                     // splitTrianglesForBox :225-272
+        const vec3 mn = h.nodes[node].minBox, mx = h.nodes[node].maxBox;
+        const uint32_t first = h.nodes[node].first, n = h.nodes[node].count;
+        const float sx = std::fabs(mx.x - mn.x), sy = std::fabs(mx.y - mn.y), sz = std::fabs(mx.z - mn.z);
+        auto b = h.order.begin() + first, e = b + n;
+        if (sx > sy && sx > sz)      std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.x < tris[c].pointOne.x; });
+        else if (sy > sx && sy > sz) std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.y < tris[c].pointOne.y; });
+        else                         std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.z < tris[c].pointOne.z; });
+        const uint32_t nl = n / 2, nr = n - nl;
+        Node L, R;
+        L.first = first; L.count = nl; bounds(L.first, L.count, L.minBox, L.maxBox);
+        R.first = first + nl; R.count = nr; bounds(R.first, R.count, R.minBox, R.maxBox);
+        const int32_t li = (int32_t)h.nodes.size();
+        h.nodes[node].left = li; h.nodes.push_back(L);
+        if (nl > 8) split(li);                                                     // triangleSizeStop = 8 (:261)
+        const int32_t ri = (int32_t)h.nodes.size();
+        h.nodes[node].right = ri; h.nodes.push_back(R);
+        if (nr > 8) split(ri);
+    }
+};
+} // namespace
+
+void ObjectManager::createBoundingHierarchy(const std::string& objFilename) {
+    std::vector<Triangle>& triangles = objTriangles[objFilename];
+    Hierarchy h;
+    h.order.resize(triangles.size());
+    for (uint32_t i = 0; i < triangles.size(); i++) h.order[i] = i;
+    Builder b{ triangles, h };
+    Node root; root.first = 0; root.count = (uint32_t)triangles.size();
+    b.bounds(0, root.count, root.minBox, root.maxBox);
+    minBox[objFilename] = root.minBox; maxBox[objFilename] = root.maxBox;        // :280
+    h.nodes.reserve(triangles.size() / 2 + 8);
+    h.nodes.push_back(root);
+    b.split(0);                                                                  // the root is always split (:282)
+    boundingVolumeHierarchy[objFilename] = std::move(h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flattener: ObjectManager -> flat scene of include/srt.h
+// ------------------------------------------------------------------------------------------------
+srt_scene_desc FlatScene::desc() const {
+    srt_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_objects = (uint32_t)obj_root.size(); d.n_nodes = (uint32_t)node_left.size();
+    d.n_tris = (uint32_t)tri_obj.size(); d.n_textures = (uint32_t)tex_w.size();
+    d.node_min = node_min.data(); d.node_max = node_max.data();
+    d.node_left = node_left.data(); d.node_right = node_right.data(); d.node_first = node_first.data(); d.node_count = node_count.data();
+    d.obj_root = obj_root.data();
+    d.tri_points = tri_points.data(); d.tri_obj = tri_obj.data(); d.tri_tex = tri_tex.data();
+    d.tri_texcoord = tri_texcoord.data(); d.tri_normals = tri_normals.data();
+    d.obj_color = obj_color.data(); d.obj_material = obj_material.data();
+    d.tex_rgb = tex_rgb.data(); d.tex_off = tex_off.data(); d.tex_w = tex_w.data(); d.tex_h = tex_h.data();
+    return d;
+}
+
+FlatScene flattenScene(ObjectManager* om) {
+    FlatScene f;
+    std::unordered_map<std::string, int32_t> tex_id;
+    for (const auto& pair : om->objTriangles) {                 // the iteration order rayIntersection:409 uses
+        const std::string& name = pair.first;
+        auto hit = om->boundingVolumeHierarchy.find(name);
+        if (hit == om->boundingVolumeHierarchy.end())
+            throw std::runtime_error("object '" + name + "' has no bounding hierarchy (createBoundingHierarchy not called)");
+        const ObjectManager::Hierarchy& h = hit->second;
+        const std::vector<Triangle>& tris = pair.second;
+        const int32_t obj = (int32_t)f.obj_root.size();
+        const int32_t base = (int32_t)f.node_left.size();
+        f.names.push_back(name);
+        f.obj_root.push_back((uint32_t)base);
+        const vec3 c = om->objColors[name], m = om->objProperties[name];    // operator[]: default-inserts (0,0,0) like :368,439
+        f.obj_color.insert(f.obj_color.end(), { c.x, c.y, c.z });
+        f.obj_material.insert(f.obj_material.end(), { m.x, m.y, m.z });
+        for (const Node& n : h.nodes) {                          // Hierarchy::nodes is already DFS pre-order
+            f.node_min.insert(f.node_min.end(), { n.minBox.x, n.minBox.y, n.minBox.z });
+            f.node_max.insert(f.node_max.end(), { n.maxBox.x, n.maxBox.y, n.maxBox.z });
+            const bool leaf = n.left < 0 && n.right < 0;
+            f.node_left.push_back(leaf ? -1 : base + n.left);
+            f.node_right.push_back(leaf ? -1 : base + n.right);
+            f.node_first.push_back(leaf ? (int32_t)f.tri_obj.size() : -1);
+            f.node_count.push_back(leaf ? (int32_t)n.count : 0);
+            if (!leaf) continue;
+            for (uint32_t k = 0; k < n.count; k++) {
+                const Triangle& t = tris[h.order[n.first + k]];
+                const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
+                for (int j = 0; j < 3; j++) f.tri_points.insert(f.tri_points.end(), { p[j]->x, p[j]->y, p[j]->z, p[j]->w });
+                const vec2* tc[3] = { &t.colorOneCoordinate, &t.colorTwoCoordinate, &t.colorThreeCoordinate };
+                for (int j = 0; j < 3; j++) f.tri_texcoord.insert(f.tri_texcoord.end(), { tc[j]->x, tc[j]->y });
+                const vec3* nn[3] = { &t.normalOne, &t.normalTwo, &t.normalThree };
+                for (int j = 0; j < 3; j++) f.tri_normals.insert(f.tri_normals.end(), { nn[j]->x, nn[j]->y, nn[j]->z });
+                f.tri_obj.push_back(obj);
+                int32_t tid = -1;
+                if (!t.textureName.empty()) {
+                    auto ti = om->textureData.find(t.textureName);
+                    if (ti != om->textureData.end()) {
+                        auto known = tex_id.find(t.textureName);
+                        if (known == tex_id.end()) {
+                            tid = (int32_t)f.tex_w.size();
+                            tex_id[t.textureName] = tid;
+                            f.tex_names.push_back(t.textureName);
+                            f.tex_off.push_back((uint64_t)f.tex_rgb.size());
+                            f.tex_w.push_back((uint32_t)ti->second.dim.x); f.tex_h.push_back((uint32_t)ti->second.dim.y);
+                            f.tex_rgb.insert(f.tex_rgb.end(), ti->second.rgb.begin(), ti->second.rgb.end());
+                        } else tid = known->second;
+                    }
+                }
+                f.tri_tex.push_back(tid);
+            }
+        }
+    }
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Drop-in entry point and image output
+// ------------------------------------------------------------------------------------------------
+ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
+                                           int lightAmount, int device) {
+    FlatScene flat = flattenScene(objManager);
+    srt_scene_desc d = flat.desc();
+    srt_scene* scene = nullptr;
+    int rc = srt_scene_create(device, &d, &scene);
+    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_create: ") + srt_strerror(rc));
+    const uint32_t W = (uint32_t)imageSize.x, H = (uint32_t)imageSize.y;
+    srt_params p;
+    srt_params_default(&p, W, H);
+    std::vector<float> lights((size_t)lightAmount * 3);
+    const float base[3] = { lightPos.x, lightPos.y, lightPos.z };       // vec4 -> const vec3& drops w (:517 -> :405)
+    srt_light_staircase(base, (uint32_t)lightAmount, lights.data());
+    p.n_lights = (uint32_t)lightAmount; p.light_pos = lights.data();
+    const uint8_t key[3] = { 0, 0, 0 };                                  // ask for black so ImageData can skip it (:518)
+    p.background[0] = key[0]; p.background[1] = key[1]; p.background[2] = key[2];
+    std::vector<uint8_t> rgb8((size_t)W * H * 3);
+    rc = srt_render(scene, &p, nullptr, nullptr, nullptr, rgb8.data(), nullptr);
+    srt_scene_destroy(scene);
+    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_render: ") + srt_strerror(rc));
+    ImageData out;
+    for (uint32_t x = 0; x < W; x++)                                     // reference emission order: x outer (:511-513)
+        for (uint32_t y = 0; y < H; y++) {
+            const uint8_t* c = &rgb8[((size_t)y * W + x) * 3];
+            if (c[0] | c[1] | c[2]) {
+                out.imagePoints.emplace_back((float)x, (float)y);
+                out.imageColors.emplace_back((float)c[0], (float)c[1], (float)c[2]);
+            }
+        }
+    return out;
+}
+
+void writeBmp(const std::string& path, uint32_t W, uint32_t H, const uint8_t* rgb) {
+    const uint32_t stride = (W * 3 + 3) & ~3u, size = 54 + stride * H;
+    std::vector<uint8_t> f(size, 0);
+    auto le32 = [&](size_t o, uint32_t v) { f[o] = v & 255; f[o + 1] = (v >> 8) & 255; f[o + 2] = (v >> 16) & 255; f[o + 3] = (v >> 24) & 255; };
+    f[0] = 'B'; f[1] = 'M'; le32(2, size); le32(10, 54); le32(14, 40); le32(18, W); le32(22, H); f[26] = 1; f[28] = 24; le32(34, stride * H);
+    for (uint32_t y = 0; y < H; y++) {
+        uint8_t* row = &f[54 + (size_t)stride * (H - 1 - y)];
+        for (uint32_t x = 0; x < W; x++) { const uint8_t* c = &rgb[((size_t)y * W + x) * 3]; row[x * 3] = c[2]; row[x * 3 + 1] = c[1]; row[x * 3 + 2] = c[0]; }
+    }
+    std::ofstream o(path, std::ios::binary);
+    if (!o) throw std::runtime_error("cannot write " + path);
+    o.write((const char*)f.data(), (std::streamsize)f.size());
+}
+
+void drawImage(const vec2& imgSize, const std::vector<vec2>& imagePoints, const std::vector<vec3>& imageColors,
+               const int& angleDegree, const bool& saveImage, const std::string& directory) {
+    const uint32_t W = (uint32_t)imgSize.x, H = (uint32_t)imgSize.y;
+    std::vector<uint8_t> img((size_t)W * H * 3, 0);                                     // :463-464
+    for (size_t i = 0; i < imagePoints.size(); i++) {                                   // :468-474
+        const uint32_t x = (uint32_t)imagePoints[i].x, y = (uint32_t)imagePoints[i].y;
+        if (x >= W || y >= H) continue;
+        uint8_t* c = &img[((size_t)y * W + x) * 3];
+        c[0] = (uint8_t)imageColors[i].x; c[1] = (uint8_t)imageColors[i].y; c[2] = (uint8_t)imageColors[i].z;
+    }
+    for (size_t i = 0; i < (size_t)W * H; i++)                                          // :476-487
+        if (!img[i * 3] && !img[i * 3 + 1] && !img[i * 3 + 2]) { img[i * 3] = 173; img[i * 3 + 1] = 216; img[i * 3 + 2] = 230; }
+    if (saveImage) writeBmp(directory + "/output" + std::to_string(static_cast<int>(angleDegree)) + ".bmp", W, H, img.data());   // :488-494
+}
+
+} // namespace srt_host

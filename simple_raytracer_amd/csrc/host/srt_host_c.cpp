@@ -1,0 +1,117 @@
+// srt_host_c.cpp -- plain-C handles over srt_host.h so that Python (ctypes) tests, bench.py and other
+// FFI users can drive the host-side mirror.  No compute here; exceptions never cross the boundary.
+#include <cstring>
+#include <string>
+
+#include "srt_host.h"
+
+using namespace srt_host;
+
+static thread_local std::string g_err;
+#define GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown"; return -1; }
+
+static mat4 to_mat(const float* m) { mat4 M; std::memcpy(&M[0][0], m, 64); return M; }
+static void from_mat(const mat4& M, float* m) { std::memcpy(m, &M[0][0], 64); }
+
+extern "C" {
+
+const char* srth_last_error() { return g_err.c_str(); }
+
+void* srth_om_new() { return new ObjectManager(); }
+void srth_om_free(void* om) { delete (ObjectManager*)om; }
+int srth_om_load_obj(void* om, const char* name) { GUARD(((ObjectManager*)om)->loadObjFile(name)) }
+
+// Object fed from arrays with the loader's defaults (Object.cpp:29-34, 81-84)
+int srth_om_add_object(void* om_, const char* name, uint32_t n, const float* points) {
+    GUARD({
+        ObjectManager* om = (ObjectManager*)om_;
+        om->objColors[name] = vec3(1.f, 0.f, 0.f);
+        om->objProperties[name] = vec3(0.2f, 0.5f, 15.0f);
+        std::vector<Triangle> tris(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const float* p = points + (size_t)i * 12;
+            tris[i].pointOne = vec4(p[0], p[1], p[2], p[3]); tris[i].pointTwo = vec4(p[4], p[5], p[6], p[7]); tris[i].pointThree = vec4(p[8], p[9], p[10], p[11]);
+            tris[i].color = vec3(1.f, 1.f, 1.f);
+        }
+        om->setTriangles(name, tris);
+    })
+}
+// objTriangles[dst] = getTriangles(src), as main() clones objects (simple_raytracer.cpp:565,597,644)
+int srth_om_clone(void* om_, const char* src, const char* dst) {
+    GUARD({ ObjectManager* om = (ObjectManager*)om_; std::vector<Triangle> t = om->getTriangles(src); om->objTriangles[dst] = t; })
+}
+int srth_om_set_color(void* om, const char* name, float r, float g, float b) { GUARD(((ObjectManager*)om)->setColor(name, vec3(r, g, b))) }
+int srth_om_set_props(void* om, const char* name, float ka, float ks, float sh) { GUARD(((ObjectManager*)om)->objProperties[name] = vec3(ka, ks, sh)) }
+int srth_om_transform(void* om, const char* name, const float* m) { GUARD(((ObjectManager*)om)->transformTriangles(name, to_mat(m))) }
+int srth_om_build_bvh(void* om, const char* name) { GUARD(((ObjectManager*)om)->createBoundingHierarchy(name)) }
+int64_t srth_om_num_tris(void* om, const char* name) {
+    try { return (int64_t)((ObjectManager*)om)->getTriangles(name).size(); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int srth_om_get_points(void* om, const char* name, float* out) {
+    GUARD({
+        const std::vector<Triangle>& v = ((ObjectManager*)om)->getTriangles(name);
+        for (size_t i = 0; i < v.size(); i++) {
+            const vec4* p[3] = { &v[i].pointOne, &v[i].pointTwo, &v[i].pointThree };
+            for (int k = 0; k < 3; k++) for (int c = 0; c < 4; c++) out[(i * 3 + k) * 4 + c] = (*p[k])[c];
+        }
+    })
+}
+int srth_om_get_tri_attrs(void* om, const char* name, float* texcoord, float* color, int32_t* has_tex, float* normals) {
+    GUARD({
+        const std::vector<Triangle>& v = ((ObjectManager*)om)->getTriangles(name);
+        for (size_t i = 0; i < v.size(); i++) {
+            const vec2* tc[3] = { &v[i].colorOneCoordinate, &v[i].colorTwoCoordinate, &v[i].colorThreeCoordinate };
+            for (int k = 0; k < 3; k++) { texcoord[i * 6 + k * 2] = tc[k]->x; texcoord[i * 6 + k * 2 + 1] = tc[k]->y; }
+            color[i * 3] = v[i].color.x; color[i * 3 + 1] = v[i].color.y; color[i * 3 + 2] = v[i].color.z;
+            has_tex[i] = v[i].textureName.empty() ? 0 : 1;
+            const vec3* nn[3] = { &v[i].normalOne, &v[i].normalTwo, &v[i].normalThree };
+            for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) normals[i * 9 + k * 3 + c] = (*nn[k])[c];
+        }
+    })
+}
+
+// ---- flattener ---------------------------------------------------------------------------------
+void* srth_flatten(void* om) {
+    try { return new FlatScene(flattenScene((ObjectManager*)om)); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void srth_flat_free(void* f) { delete (FlatScene*)f; }
+void srth_flat_desc(void* f, srt_scene_desc* out) { *out = ((FlatScene*)f)->desc(); }
+uint32_t srth_flat_names(void* f_, char* buf, uint32_t cap) {
+    FlatScene* f = (FlatScene*)f_;
+    std::string s;
+    for (const auto& n : f->names) { s += n; s += '\n'; }
+    if (cap) { std::strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return (uint32_t)f->names.size();
+}
+
+// ---- drop-in entry point (GPU) + writer -----------------------------------------------------------
+// Dense H x W x 3 float image like oracle/ref_harness.cpp's ref_render: 0 where nothing was emitted.
+int64_t srth_render(void* om, uint32_t W, uint32_t H, const float* light4, int light_amount, int device, float* rgb) {
+    try {
+        ImageData d = sendRaysAndIntersectPointsColors(vec2((float)W, (float)H), vec4(light4[0], light4[1], light4[2], light4[3]),
+                                                       (ObjectManager*)om, light_amount, device);
+        std::memset(rgb, 0, (size_t)W * H * 3 * sizeof(float));
+        for (size_t i = 0; i < d.imagePoints.size(); i++) {
+            const size_t x = (size_t)d.imagePoints[i].x, y = (size_t)d.imagePoints[i].y;
+            rgb[(y * W + x) * 3] = d.imageColors[i].x; rgb[(y * W + x) * 3 + 1] = d.imageColors[i].y; rgb[(y * W + x) * 3 + 2] = d.imageColors[i].z;
+        }
+        return (int64_t)d.imagePoints.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int srth_write_bmp(const char* path, uint32_t W, uint32_t H, const uint8_t* rgb) { GUARD(writeBmp(path, W, H, rgb)) }
+
+// ---- Transformation.h factories + the glm ops main() applies --------------------------------------
+float srth_radians(float d) { return radians(d); }
+void srth_mat_scale(float x, float y, float z, float* m) { from_mat(Transformation::scaleObj(x, y, z), m); }
+void srth_mat_rotx(float a, float* m) { from_mat(Transformation::rotateObjX(a), m); }
+void srth_mat_roty(float a, float* m) { from_mat(Transformation::rotateObjY(a), m); }
+void srth_mat_rotz(float a, float* m) { from_mat(Transformation::rotateObjZ(a), m); }
+void srth_mat_mirror(int x, int y, int z, float* m) { from_mat(Transformation::mirrorObj(x, y, z), m); }
+void srth_mat_shear(float xy, float xz, float yx, float yz, float zx, float zy, float* m) { from_mat(Transformation::shearObj(xy, xz, yx, yz, zx, zy), m); }
+void srth_mat_translate(float x, float y, float z, float* m) { from_mat(Transformation::changeObjPosition(vec3(x, y, z)), m); }
+void srth_mat_view(const float* pos, const float* rot, float* m) { from_mat(Transformation::createViewMatrix(vec3(pos[0], pos[1], pos[2]), vec3(rot[0], rot[1], rot[2])), m); }
+void srth_mat_inverse(const float* a, float* m) { from_mat(inverse(to_mat(a)), m); }
+void srth_mat_mul(const float* a, const float* b, float* m) { from_mat(to_mat(a) * to_mat(b), m); }
+void srth_mat_mul_vec4(const float* a, const float* v, float* out) { vec4 r = to_mat(a) * vec4(v[0], v[1], v[2], v[3]); std::memcpy(out, &r.x, 16); }
+
+} // extern "C"

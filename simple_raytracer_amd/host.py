@@ -1,0 +1,225 @@
+"""ctypes binding of libsrt_host.so: the host-side C++ mirror of the reference's scene interface
+(ObjectManager / Transformation / sendRaysAndIntersectPointsColors; csrc/host/srt_host.h).
+
+Scene construction, transforms, the hierarchy builder and the flattener run on the host CPU as they
+do in the reference; only `render()` (the drop-in for sendRaysAndIntersectPointsColors) goes to the
+GPU, through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrt_host.so")
+_f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run python -m simple_raytracer_amd.build")
+        L = C.CDLL(LIB_PATH)
+        L.srth_last_error.restype = C.c_char_p
+        L.srth_om_new.restype = C.c_void_p
+        L.srth_om_free.argtypes = [C.c_void_p]
+        for fn in ("srth_om_load_obj", "srth_om_build_bvh"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_char_p]
+        L.srth_om_add_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p]
+        L.srth_om_clone.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.srth_om_set_color.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
+        L.srth_om_set_props.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
+        L.srth_om_transform.argtypes = [C.c_void_p, C.c_char_p, _f32p]
+        L.srth_om_num_tris.argtypes = [C.c_void_p, C.c_char_p]
+        L.srth_om_num_tris.restype = C.c_int64
+        L.srth_om_get_points.argtypes = [C.c_void_p, C.c_char_p, _f32p]
+        L.srth_om_get_tri_attrs.argtypes = [C.c_void_p, C.c_char_p, _f32p, _f32p, _i32p, _f32p]
+        L.srth_flatten.argtypes = [C.c_void_p]
+        L.srth_flatten.restype = C.c_void_p
+        L.srth_flat_free.argtypes = [C.c_void_p]
+        L.srth_flat_desc.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc)]
+        L.srth_flat_names.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.srth_flat_names.restype = C.c_uint32
+        L.srth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _f32p, C.c_int, C.c_int, _f32p]
+        L.srth_render.restype = C.c_int64
+        L.srth_write_bmp.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u8p]
+        L.srth_radians.argtypes = [C.c_float]
+        L.srth_radians.restype = C.c_float
+        for name in ("srth_mat_rotx", "srth_mat_roty", "srth_mat_rotz"):
+            getattr(L, name).argtypes = [C.c_float, _f32p]
+        L.srth_mat_scale.argtypes = [C.c_float] * 3 + [_f32p]
+        L.srth_mat_translate.argtypes = [C.c_float] * 3 + [_f32p]
+        L.srth_mat_shear.argtypes = [C.c_float] * 6 + [_f32p]
+        L.srth_mat_mirror.argtypes = [C.c_int] * 3 + [_f32p]
+        L.srth_mat_view.argtypes = [_f32p, _f32p, _f32p]
+        L.srth_mat_inverse.argtypes = [_f32p, _f32p]
+        L.srth_mat_mul.argtypes = [_f32p, _f32p, _f32p]
+        L.srth_mat_mul_vec4.argtypes = [_f32p, _f32p, _f32p]
+        _lib = L
+    return _lib
+
+
+def _p(a, ty=_f32p):
+    return a.ctypes.data_as(ty)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _ok(rc):
+    if rc != 0:
+        raise HostError(load().srth_last_error().decode())
+
+
+class Transformation:
+    """Transformation.h:10-20 of the reference (same factory names) + the glm ops main() applies.
+    Matrices are 16 floats, column-major (glm::mat4 memory order)."""
+
+    @staticmethod
+    def _m(fn, *a):
+        out = np.empty(16, np.float32); fn(*a, _p(out)); return out
+
+    @staticmethod
+    def radians(d): return float(load().srth_radians(d))
+    @staticmethod
+    def scaleObj(x, y, z): return Transformation._m(load().srth_mat_scale, x, y, z)
+    @staticmethod
+    def rotateObjX(a): return Transformation._m(load().srth_mat_rotx, a)
+    @staticmethod
+    def rotateObjY(a): return Transformation._m(load().srth_mat_roty, a)
+    @staticmethod
+    def rotateObjZ(a): return Transformation._m(load().srth_mat_rotz, a)
+    @staticmethod
+    def mirrorObj(x, y, z): return Transformation._m(load().srth_mat_mirror, int(x), int(y), int(z))
+    @staticmethod
+    def shearObj(*s): return Transformation._m(load().srth_mat_shear, *s)
+    @staticmethod
+    def changeObjPosition(x, y, z): return Transformation._m(load().srth_mat_translate, x, y, z)
+
+    @staticmethod
+    def createViewMatrix(pos, rot):
+        pos, rot, out = _f(pos), _f(rot), np.empty(16, np.float32)
+        load().srth_mat_view(_p(pos), _p(rot), _p(out)); return out
+
+    @staticmethod
+    def inverse(m):
+        m, out = _f(m), np.empty(16, np.float32); load().srth_mat_inverse(_p(m), _p(out)); return out
+
+    @staticmethod
+    def mul(a, b):
+        a, b, out = _f(a), _f(b), np.empty(16, np.float32); load().srth_mat_mul(_p(a), _p(b), _p(out)); return out
+
+    @staticmethod
+    def mul_vec4(a, v):
+        a, v, out = _f(a), _f(v), np.empty(4, np.float32); load().srth_mat_mul_vec4(_p(a), _p(v), _p(out)); return out
+
+    # aliases with the provider names tests/scenes.py uses for both this class and the reference's
+    scale, rotx, roty, rotz, mirror, shear, translate, view = scaleObj, rotateObjX, rotateObjY, rotateObjZ, mirrorObj, shearObj, changeObjPosition, createViewMatrix
+
+
+class ObjectManager:
+    """Object.h:59-89 of the reference: string-keyed objects, loadObjFile / transformTriangles /
+    createBoundingHierarchy / setColor, plus flatten() (the flat scene of include/srt.h) and render()
+    (drop-in for sendRaysAndIntersectPointsColors, on the GPU)."""
+
+    def __init__(self):
+        self.L = load()
+        self.om = C.c_void_p(self.L.srth_om_new())
+
+    def __del__(self):
+        try:
+            if self.om:
+                self.L.srth_om_free(self.om); self.om = None
+        except Exception:
+            pass
+
+    def loadObjFile(self, name): _ok(self.L.srth_om_load_obj(self.om, name.encode()))
+
+    def add_object(self, name, points):
+        pts = _f(points).reshape(-1, 12)
+        _ok(self.L.srth_om_add_object(self.om, name.encode(), pts.shape[0], _p(pts)))
+
+    def clone(self, src, dst): _ok(self.L.srth_om_clone(self.om, src.encode(), dst.encode()))
+    def setColor(self, name, rgb): _ok(self.L.srth_om_set_color(self.om, name.encode(), *[float(x) for x in rgb]))
+    def set_props(self, name, p): _ok(self.L.srth_om_set_props(self.om, name.encode(), *[float(x) for x in p]))
+    def transformTriangles(self, name, m): m = _f(m); _ok(self.L.srth_om_transform(self.om, name.encode(), _p(m)))
+    def createBoundingHierarchy(self, name): _ok(self.L.srth_om_build_bvh(self.om, name.encode()))
+    set_color, transform, build_bvh, load_obj = setColor, transformTriangles, createBoundingHierarchy, loadObjFile
+
+    def num_tris(self, name):
+        n = self.L.srth_om_num_tris(self.om, name.encode())
+        if n < 0:
+            raise KeyError(name)          # std::out_of_range from objTriangles.at(), Object.cpp:174
+        return int(n)
+
+    def points(self, name):
+        out = np.empty((self.num_tris(name), 3, 4), np.float32)
+        _ok(self.L.srth_om_get_points(self.om, name.encode(), _p(out))); return out
+
+    def tri_attrs(self, name):
+        n = self.num_tris(name)
+        tc, col, ht, nrm = np.empty((n, 6), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.int32), np.empty((n, 9), np.float32)
+        _ok(self.L.srth_om_get_tri_attrs(self.om, name.encode(), _p(tc), _p(col), _p(ht, _i32p), _p(nrm))); return tc, col, ht, nrm
+
+    def flatten(self) -> abi.FlatScene:
+        h = self.L.srth_flatten(self.om)
+        if not h:
+            raise HostError(self.L.srth_last_error().decode())
+        try:
+            d = abi.SceneDesc(); self.L.srth_flat_desc(h, C.byref(d))
+            buf = C.create_string_buffer(1 << 16); self.L.srth_flat_names(h, buf, 1 << 16)
+            names = [s for s in buf.value.decode().split("\n") if s]
+
+            def arr(ptr, n, dt):
+                return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+            no, nn, nt, nx = d.n_objects, d.n_nodes, d.n_tris, d.n_textures
+            kw = {}
+            if nx:
+                tex_off = arr(d.tex_off, nx, np.uint64); tex_w = arr(d.tex_w, nx, np.uint32); tex_h = arr(d.tex_h, nx, np.uint32)
+                total = int(max(int(o) + int(w) * int(h_) * 3 for o, w, h_ in zip(tex_off, tex_w, tex_h)))
+                kw = dict(tex_rgb=arr(d.tex_rgb, total, np.uint8), tex_off=tex_off, tex_w=tex_w, tex_h=tex_h)
+            return abi.FlatScene(
+                node_min=arr(d.node_min, nn * 3, np.float32).reshape(nn, 3), node_max=arr(d.node_max, nn * 3, np.float32).reshape(nn, 3),
+                node_left=arr(d.node_left, nn, np.int32), node_right=arr(d.node_right, nn, np.int32),
+                node_first=arr(d.node_first, nn, np.int32), node_count=arr(d.node_count, nn, np.int32),
+                obj_root=arr(d.obj_root, no, np.uint32),
+                tri_points=arr(d.tri_points, nt * 12, np.float32).reshape(nt, 3, 4), tri_obj=arr(d.tri_obj, nt, np.int32),
+                tri_tex=arr(d.tri_tex, nt, np.int32), tri_texcoord=arr(d.tri_texcoord, nt * 6, np.float32).reshape(nt, 6),
+                tri_normals=arr(d.tri_normals, nt * 9, np.float32).reshape(nt, 9),
+                obj_color=arr(d.obj_color, no * 3, np.float32).reshape(no, 3), obj_material=arr(d.obj_material, no * 3, np.float32).reshape(no, 3),
+                names=names, **kw)
+        finally:
+            self.L.srth_flat_free(h)
+
+    def render(self, W, H, light4, light_amount=1, device=0):
+        """sendRaysAndIntersectPointsColors drop-in (GPU): dense H x W x 3 float image of the emitted
+        (px,py,rgb) list, 0 where nothing was emitted; returns (image, n_emitted)."""
+        light4 = _f(light4)
+        rgb = np.empty((H, W, 3), np.float32)
+        n = self.L.srth_render(self.om, W, H, _p(light4), light_amount, device, _p(rgb))
+        if n < 0:
+            raise HostError(self.L.srth_last_error().decode())
+        return rgb, int(n)
+
+
+def write_bmp(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    _ok(load().srth_write_bmp(path.encode(), rgb8.shape[1], rgb8.shape[0], _p(rgb8, _u8p)))
+
+
+def build_flat_scene(recipe, meshes) -> abi.FlatScene:
+    """Replay a tests/scenes.Recipe on the host ObjectManager and flatten it."""
+    om = ObjectManager()
+    recipe.replay(om, meshes)
+    return om.flatten()

@@ -101,9 +101,9 @@ def test_soup_scene_matches_oracle(srt, oracle):
     """Synthetic triangle soup (BASELINE config 5 generator) at a size the oracle finishes in seconds:
     4 objects, cross-object shadows, built by the oracle-side reference-free path."""
     import scenes
-    from tests_support import build_flat_scene
+    from simple_raytracer_amd import host
     recipe, meshes = scenes.soup(20000)
-    flat = build_flat_scene(recipe, meshes)
+    flat = host.build_flat_scene(recipe, meshes)
     ds = srt.DeviceScene(flat)
     p = abi.make_params(512, 512, abi.light_staircase(recipe.light, 2), flags=abi.SRT_FLAG_COUNT_WORK)
     o = ds.render(p); c = oracle.render(flat, p)
@@ -130,3 +130,19 @@ def test_bad_scene_is_rejected_not_faulted(srt):
     _, ds = device_scene(srt, "cube")
     with pytest.raises(srt.SrtError):
         ds.render(p)
+
+
+def test_dropin_entry_point_matches_reference_image(srt):
+    """The host-side drop-in for sendRaysAndIntersectPointsColors (C++ mirror -> flatten -> C ABI -> HIP)
+    returns the (px, py, rgb) list the reference returned (golden rgb8 = reference list + drawImage rule)."""
+    from simple_raytracer_amd import host
+    for name, (W, H) in (("cubes4_a0", (256, 256)), ("ground_bunny", (192, 108))):
+        g = gu.GoldenScene(name)
+        om = host.ObjectManager()
+        g.recipe.replay(om, {k: gu.load_mesh(k) for k in g.recipe.meshes})
+        img, n = om.render(W, H, list(g.light) + [1.0])
+        q = img.astype(np.int32)
+        q[q.sum(-1) == 0] = abi.REFERENCE_BACKGROUND
+        check_rgb8(q.astype(np.uint8), g.out(W, H, 1, "rgb8"))
+        want = g.out(W, H, 1, "rgb8")
+        assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2

@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py -- block-cyclic scanline ownership + one
+gather to rank 0 + de-interleave (simple_raytracer_amd/tiling.py).  The tiles are produced by the CPU
+oracle here (no GPU in this container); on the GPU box the same FrameGather carries the HIP output."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, block_rows, W, H, L, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import golden_util as gu
+        from oracle import pyoracle as po
+        from simple_raytracer_amd import abi, tiling
+        g = gu.GoldenScene("cubes4_a0")
+        lights = abi.light_staircase(g.light, L)
+        p = tiling.split_params(W, H, lights, rank, world, block_rows)
+        o = po.render(g.flat, p, n_threads=1)
+        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"))
+        assert fg.rows == o["rgb8"].shape[0]
+        fg.tile[: fg.rows].copy_(torch.from_numpy(o["rgb8"]))
+        frame = fg.gather()
+        hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32)
+        hg.tile[: hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
+        hits = hg.gather()
+        if rank == 0:
+            q.put((frame.numpy().copy(), hits.numpy()[..., 0].copy()))
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block_rows", [(2, 16), (2, 7), (3, 5)])
+def test_gather_reassembles_reference_frame(world, block_rows):
+    import golden_util as gu
+    W, H, L = 128, 96, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, block_rows, W, H, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame, hits = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = gu.GoldenScene("cubes4_a0")
+    assert np.array_equal(frame, g.out(W, H, L, "rgb8")), "tiled + gathered frame differs from the reference image"
+    assert np.array_equal(hits, g.out(W, H, L, "hit_id"))
