@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
     args = ap.parse_args()
 
     import torch
@@ -68,7 +69,7 @@ def main():
     scene = lib.DeviceScene(g.flat, device=local_rank)
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
-    p = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS)
+    p = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS, flags=args.variant << 8)
     rows = scene.rows(p)
     dev = torch.device("cuda", local_rank)
     hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
@@ -107,7 +108,7 @@ def main():
 
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
-                         flags=abi.SRT_FLAG_COUNT_WORK)
+                         flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8))
     scene.render_device(pc, stream=stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(), rgb_linear=lin.data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
@@ -123,13 +124,21 @@ def main():
 
     if rank == 0:
         pixels = W * rows
+        hits, miss = sc["hit_rays"], pixels - sc["hit_rays"]
+        items = hits * L
+        # algorithmic bytes per launch: 32 B per slab test + 36 B per Moller-Trumbore test of the kernel's own
+        # traversal + the per-pixel / per-item records each kernel must read and write
         kern = {
-            "k_closest_hit": dict(ms=st["ms_primary"],
-                                  bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"] + 8 * pixels),
-            "k_shade": dict(ms=st["ms_shade"],
-                            bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 12 * sc["hit_rays"]
-                            + (8 + 15) * pixels),
+            "k_closest_hit_q": dict(ms=st["ms_primary"],
+                                    bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"]
+                                    + 8 * pixels + 15 * miss),
+            "k_shadow": dict(ms=st["ms_shadow"],
+                             bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8),
+            "k_shade_tile": dict(ms=st["ms_shade"], bytes=4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8),
         }
+        if args.variant == 1:
+            kern = {"k_closest_hit": dict(ms=st["ms_primary"], bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"] + 8 * pixels),
+                    "k_shade": dict(ms=st["ms_shade"], bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 12 * hits + 23 * pixels)}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         achieved = kern[dom]["bytes"] / (kern[dom]["ms"] * 1e-3) / 1e9 if kern[dom]["ms"] > 0 else 0.0
         out = {

@@ -114,7 +114,8 @@ typedef struct srt_stats {
     /* HIP-event times on the launch stream, AVERAGED over the `launches` renders since the previous
      * srt_sync (at most 64 are kept; older ones are dropped from the average) */
     float    ms_primary;           /* closest-hit kernel                                            */
-    float    ms_shade;             /* shadow + shading kernel                                       */
+    float    ms_shadow;            /* shadow-ray kernel                                             */
+    float    ms_shade;             /* shading kernel                                                */
     float    ms_total;             /* first launch -> last kernel done                              */
     uint32_t launches;
     uint32_t rows;                 /* rows written by the last render                               */

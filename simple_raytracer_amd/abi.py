@@ -50,7 +50,7 @@ class Stats(C.Structure):
         ("primary_rays", C.c_uint64), ("hit_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
         ("node_tests_primary", C.c_uint64), ("tri_tests_primary", C.c_uint64),
         ("node_tests_shadow", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
-        ("ms_primary", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
+        ("ms_primary", C.c_float), ("ms_shadow", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
         ("launches", C.c_uint32), ("rows", C.c_uint32),
     ]
 

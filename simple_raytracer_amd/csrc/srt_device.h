@@ -72,6 +72,23 @@ __device__ __forceinline__ bool ray_aabb(V3 o, V3 d, float mnx, float mny, float
     return true;
 }
 
+// Same predicate without the early return: all six quotients first (so that a node is fetched as two
+// dwordx4 and divergent lanes do not serialise on the xy-reject branch).  The z terms are only
+// consulted when the xy test did not reject, exactly as the reference's control flow does.
+__device__ __forceinline__ bool ray_aabb_nb(V3 o, V3 d, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+    float minX = (mnx - o.x) / d.x, maxX = (mxx - o.x) / d.x;
+    float minY = (mny - o.y) / d.y, maxY = (mxy - o.y) / d.y;
+    float minZ = (mnz - o.z) / d.z, maxZ = (mxz - o.z) / d.z;
+    if (minX > maxX) { float s = minX; minX = maxX; maxX = s; }
+    if (minY > maxY) { float s = minY; minY = maxY; maxY = s; }
+    if (minZ > maxZ) { float s = minZ; minZ = maxZ; maxZ = s; }
+    const bool rej_xy = (maxX < minY) | (maxY < minX);
+    if (minY > minX) minX = minY;
+    if (maxY < maxX) maxX = maxY;
+    const bool rej_z = (minX > maxZ) | (minZ > maxX);
+    return !(rej_xy | rej_z);
+}
+
 // ---- a5: rayTriangleIntersection, simple_raytracer.cpp:42-75 (Moller-Trumbore) ------------------
 // Returns -inf on a miss, t >= 0 on a hit, NaN when NaN falls through every test (as the reference).
 __device__ __forceinline__ float ray_triangle(V3 o, V3 d, V3 p1, V3 e1, V3 e2) {

@@ -18,211 +18,7 @@
 
 using namespace srt;
 
-// =================================================================================================
-// Device-side scene / params views (passed by value in kernarg SGPRs)
-// =================================================================================================
-struct DevScene {
-    const DevNode* nodes;
-    const DevTri* tris;
-    const int32_t* tri_obj;
-    const int32_t* tri_tex;       // may be null (no textures)
-    const float* tri_tc;          // n_tris x 6, may be null
-    const float* obj_color;       // n_objects x 3
-    const float* obj_mat;         // n_objects x 3
-    const int2* obj_range;        // n_objects: [first node, end node) in pre-order
-    const uint8_t* tex;
-    const unsigned long long* tex_off;
-    const uint32_t* tex_w;
-    const uint32_t* tex_h;
-    const unsigned long long* tex_size;
-    uint32_t n_nodes, n_tris, n_objects;
-};
-
-struct DevParams {
-    uint32_t W, H, rows;
-    uint32_t block_rows, block_first, block_stride;
-    int32_t i0, j0;
-    float focal;
-    uint32_t n_lights;
-    const float* lights;          // device, n_lights x 3
-    float shadow_div, reinhard, gamma;
-    uint32_t bg;                  // r | g << 8 | b << 16
-};
-
-// counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
-__device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
-}
-
-// 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
-// a wave are neighbours, so they walk the same top-of-tree nodes (loads of one node by many lanes
-// coalesce into one 32 B fetch) and diverge only deep in the tree.
-__device__ __forceinline__ bool tile_pixel(const DevParams& p, uint32_t& px, uint32_t& r) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    r  = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    return px < p.W && r < p.rows;
-}
-// local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
-__device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
-    return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
-}
-// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
-__device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
-    return mk((float)(p.i0 + (int)px) + 0.0f, (float)(p.j0 + (int)y) + 0.0f, p.focal);
-}
-
-// =================================================================================================
-// Kernel 1: closest hit.  rayIntersection:405-431 with boundingBoxIntersection:296-317 fused in:
-// walk ALL slab-passing nodes of ALL objects in pre-order (== reference visit order), test leaf
-// triangles in stored order, strict '<' keeps the first (lowest id) of equal t.  No t-pruning: the
-// reference has none and its slab test may cull what Moller-Trumbore would hit, so the candidate
-// set must be reproduced exactly.
-// =================================================================================================
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_closest_hit(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
-                                                     float* __restrict__ t_out, unsigned long long* __restrict__ counters) {
-    uint32_t px, r;
-    const bool live = tile_pixel(p, px, r);
-    unsigned long long n_node = 0, n_tri = 0;
-    float best = __builtin_inff();
-    int32_t best_id = -1;
-    if (live) {
-        const V3 o = mk(0.0f, 0.0f, 0.0f);
-        const V3 d = primary_dir(p, px, image_row(p, r));
-        const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
-        const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
-        int32_t i = 0;
-        const int32_t n = (int32_t)s.n_nodes;
-        while (i < n) {
-            const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
-            const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
-            if (COUNT) n_node++;
-            if (ray_aabb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
-                if (leaf >= 0) {
-                    const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
-                    for (int32_t k = 0; k < cnt; k++) {
-                        const size_t ti = (size_t)(first + k) * 3;
-                        const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-                        const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-                        if (COUNT) n_tri++;
-                        const float t = ray_triangle(o, d, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
-                        if (t != SRT_NEG_INF && t < best) { best = t; best_id = first + k; }
-                    }
-                }
-                i = i + 1;
-            } else {
-                i = skip;
-            }
-        }
-        const size_t pix = (size_t)r * p.W + px;
-        hit_id[pix] = best_id;
-        t_out[pix] = best;
-    }
-    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
-}
-
-// =================================================================================================
-// Kernel 2: shadow rays + shading + tone map.  softShadow:348-401 -> shadowIntersection:321-342 +
-// phongIllumination:144-200, then the quantiser (:447-449) and the black -> background rule
-// (:518, drawImage:476-487).  Shading runs once, for the closest hit (the reference re-shades every
-// improving hit and keeps the last: same value).  The hit object's own tree is skipped (the reference
-// walks it and discards the result, :328/:331) and the any-hit walk exits at the first hit.
-// =================================================================================================
-template <bool COUNT>
-__device__ __forceinline__ bool any_hit(const DevScene& s, int32_t self_obj, V3 so, V3 sd,
-                                        unsigned long long& n_node, unsigned long long& n_tri) {
-    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
-    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
-    const int2 self = s.obj_range[self_obj];
-    int32_t i = 0;
-    const int32_t n = (int32_t)s.n_nodes;
-    while (i < n) {
-        if (i == self.x) { i = self.y; continue; }
-        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
-        const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
-        if (COUNT) n_node++;
-        if (ray_aabb(so, sd, a.x, a.y, a.z, a.w, b.x, b.y)) {
-            if (leaf >= 0) {
-                const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
-                for (int32_t k = 0; k < cnt; k++) {
-                    const size_t ti = (size_t)(first + k) * 3;
-                    const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-                    const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-                    if (COUNT) n_tri++;
-                    const float t = ray_triangle(so, sd, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
-                    if (t != SRT_NEG_INF) return true;       // any t >= 0, NaN included (:335)
-                }
-            }
-            i = i + 1;
-        } else {
-            i = skip;
-        }
-    }
-    return false;
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
-                                               const float* __restrict__ t_in, float* __restrict__ rgb_linear,
-                                               uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
-    uint32_t px, r;
-    const bool live = tile_pixel(p, px, r);
-    unsigned long long n_node = 0, n_tri = 0;
-    bool is_hit = false;
-    if (live) {
-        const size_t pix = (size_t)r * p.W + px;
-        const int32_t id = hit_id[pix];
-        V3 sum = mk(0.0f, 0.0f, 0.0f);
-        int q0 = 0, q1 = 0, q2 = 0;
-        if (id >= 0) {
-            is_hit = true;
-            const float t = t_in[pix];
-            const V3 o = mk(0.0f, 0.0f, 0.0f);
-            const V3 d = primary_dir(p, px, image_row(p, r));
-            const int32_t obj = s.tri_obj[id];
-            const float4* tp = reinterpret_cast<const float4*>(s.tris) + (size_t)id * 3;
-            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-            const V3 nrm = mk(t2.y, t2.z, t2.w);
-            V3 color = mk(s.obj_color[obj * 3], s.obj_color[obj * 3 + 1], s.obj_color[obj * 3 + 2]);     // :437-440
-            const int32_t tex = s.tri_tex ? s.tri_tex[id] : -1;
-            if (tex >= 0) {                                                                             // :350-361
-                const V3 P = o + d * t;
-                const V3 bc = barycentric(mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, t2.x), P);
-                const float* tc = s.tri_tc + (size_t)id * 6;
-                const float tx = (bc.x * tc[0] + bc.y * tc[2]) + bc.z * tc[4];                          // :123-125
-                const float ty = (bc.x * tc[1] + bc.y * tc[3]) + bc.z * tc[5];
-                long long idx = ((long long)((int)ty * (int)s.tex_w[tex] + (int)tx)) * 3;               // :357
-                // the reference reads out of bounds here if the texel index leaves the image (UB);
-                // this kernel clamps into the texture instead of faulting
-                const long long last = (long long)s.tex_size[tex] - 3;
-                idx = idx < 0 ? 0 : (idx > last ? last : idx);
-                const uint8_t* td = s.tex + s.tex_off[tex] + idx;
-                color = mk(td[0] / 255.0f, td[1] / 255.0f, td[2] / 255.0f);
-            }
-            const float ka = s.obj_mat[obj * 3], ks = s.obj_mat[obj * 3 + 1], sh = s.obj_mat[obj * 3 + 2];
-            const V3 dt = d * t;                      // shadowIntersection:325-326: origin d*t, dir L - d*t
-            for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
-                const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-                const bool shadowed = any_hit<COUNT>(s, obj, dt, L - dt, n_node, n_tri);
-                V3 c = phong(nrm, o, d, L, color, ka, ks, sh, t);
-                if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
-                sum = sum + c;                                                                          // :370
-            }
-            q0 = quant1(tone1(sum.x, p.reinhard, p.gamma));                                             // :391-398,447-449
-            q1 = quant1(tone1(sum.y, p.reinhard, p.gamma));
-            q2 = quant1(tone1(sum.z, p.reinhard, p.gamma));
-        }
-        if (rgb_linear) { rgb_linear[pix * 3] = sum.x; rgb_linear[pix * 3 + 1] = sum.y; rgb_linear[pix * 3 + 2] = sum.z; }
-        if (rgb8) {
-            if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
-            rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
-        }
-    }
-    wave_add(counters + 0, is_hit ? 1ull : 0ull);
-    if (COUNT) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
-}
+#include "srt_kernels.h"
 
 // =================================================================================================
 // Host side of the ABI
@@ -234,7 +30,7 @@ static thread_local int g_last_hip = 0;
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return SRT_ERR_DEVICE; } \
     } while (0)
 
-constexpr int NCTR = 8;          // device work counters
+constexpr int NCTR = 8 + 8 * 64;  // device work counters: [1..4] node/tri tests, [8 + 8*shard] sharded hit counts
 constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
 
 struct srt_scene {
@@ -247,7 +43,9 @@ struct srt_scene {
     float* ws_lin = nullptr; uint8_t* ws_rgb8 = nullptr; size_t ws_out_pixels = 0;
     float* d_lights = nullptr; float* h_lights = nullptr; uint32_t lights_cap = 0, lights_valid = 0;
     unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;
-    hipEvent_t ev[RING][3] = {};
+    unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
+    int n_cu = 256;
+    hipEvent_t ev[RING][4] = {};     // start, closest-hit done, shadow done, shade done
     uint32_t ring_count = 0;         // renders since the last srt_sync
     hipEvent_t last_done = nullptr;  // ev[..][2] of the most recent render
     hipStream_t last_stream = nullptr;
@@ -347,6 +145,7 @@ int srt_scene_destroy(srt_scene* s) {
     if (s->ws_t) (void)hipFree(s->ws_t);
     if (s->ws_lin) (void)hipFree(s->ws_lin);
     if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
+    if (s->ws_shadow) (void)hipFree(s->ws_shadow);
     if (s->d_lights) (void)hipFree(s->d_lights);
     if (s->h_lights) (void)hipHostFree(s->h_lights);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -467,7 +266,10 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
     hipError_t e = hipMalloc((void**)&s->d_counters, NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
-    for (int i = 0; i < RING * 3 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i / 3][i % 3]);
+    for (int i = 0; i < RING * 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i / 4][i % 4]);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
     if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
     *out = s;
     return SRT_OK;
@@ -481,6 +283,7 @@ static int check_params(const srt_params* p) {
     if (p->spp != 1) return SRT_ERR_ARG;            // spp > 1 is an extension not built yet
     if (p->flags & SRT_FLAG_SMOOTH_NORMALS) return SRT_ERR_ARG;   // s8 f2, not built yet
     if ((uint64_t)p->width * p->height >= (1ull << 31)) return SRT_ERR_LIMIT;
+    if ((uint64_t)p->width * p->height * (p->n_lights ? p->n_lights : 1) >= (1ull << 32)) return SRT_ERR_LIMIT;   // 32-bit work-item index
     return SRT_OK;
 }
 
@@ -511,7 +314,8 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     if (!d_t) d_t = s->ws_t;
     if (p->n_lights > s->lights_cap) {
         if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
-        if (s->d_lights) (void)hipFree(s->d_lights);
+        if (s->ws_shadow) (void)hipFree(s->ws_shadow);
+    if (s->d_lights) (void)hipFree(s->d_lights);
         if (s->h_lights) (void)hipHostFree(s->h_lights);
         s->d_lights = nullptr; s->h_lights = nullptr; s->lights_cap = 0;
         HIP_TRY(hipMalloc((void**)&s->d_lights, (size_t)p->n_lights * 3 * sizeof(float)));
@@ -537,17 +341,43 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
 
     const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
+    const uint32_t variant = (p->flags >> 8) & 0xffu;      // experimental kernel selector (0 = shipped pipeline)
+    // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
+    const size_t shadow_words = (size_t)grid.x * grid.y * 4 * (p->n_lights ? p->n_lights : 1);
+    if (variant != 1 && s->ws_shadow_words < shadow_words) {
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        if (s->ws_shadow) (void)hipFree(s->ws_shadow);
+        s->ws_shadow = nullptr; s->ws_shadow_words = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws_shadow, shadow_words * sizeof(unsigned long long)));
+        s->ws_shadow_words = shadow_words;
+    }
     hipEvent_t* ev = s->ev[s->ring_count % RING];
     HIP_TRY(hipEventRecord(ev[0], stream));
-    if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
-    else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[1], stream));
-    if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
-    else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[2], stream));
-    s->last_done = ev[2];
+    if (variant == 1) {                // v0 reference kernels: per-lane walk with inline triangle loop, per-pixel shade
+        if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
+        else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        HIP_TRY(hipGetLastError());
+    } else {
+        if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        if (p->n_lights) {
+            if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            else       hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, d_rgb_linear, d_rgb8);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ev[3], stream));
+    s->last_done = ev[3];
     s->ring_count++;
     HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     s->last_stream = stream;
@@ -562,20 +392,24 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
         HIP_TRY(hipSetDevice(s->device));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         const uint32_t n = s->ring_count < RING ? s->ring_count : RING;
-        double a = 0., b = 0., c = 0.;
+        double a = 0., b = 0., c = 0., sh = 0.;
         for (uint32_t k = 0; k < n; k++) {
             hipEvent_t* ev = s->ev[(s->ring_count - 1 - k) % RING];
-            float x = 0.f, y = 0.f, z = 0.f;
+            float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
             HIP_TRY(hipEventElapsedTime(&x, ev[0], ev[1]));
             HIP_TRY(hipEventElapsedTime(&y, ev[1], ev[2]));
-            HIP_TRY(hipEventElapsedTime(&z, ev[0], ev[2]));
-            a += x; b += y; c += z;
+            HIP_TRY(hipEventElapsedTime(&w, ev[2], ev[3]));
+            HIP_TRY(hipEventElapsedTime(&z, ev[0], ev[3]));
+            a += x; b += y; c += z; sh += w;
         }
-        s->last.ms_primary = (float)(a / n); s->last.ms_shade = (float)(b / n); s->last.ms_total = (float)(c / n);
+        s->last.ms_primary = (float)(a / n); s->last.ms_shadow = (float)(b / n); s->last.ms_shade = (float)(sh / n);
+        s->last.ms_total = (float)(c / n);
         s->last.launches = n;
         s->ring_count = 0;
-        s->last.hit_rays = s->h_counters[0];
-        s->last.shadow_rays = s->last.shadow_rays * s->h_counters[0];
+        unsigned long long hits = 0;
+        for (int k = 0; k < 64; k++) hits += s->h_counters[8 + 8 * k];
+        s->last.hit_rays = hits;
+        s->last.shadow_rays = s->last.shadow_rays * hits;
         s->last.node_tests_primary = s->h_counters[1];
         s->last.tri_tests_primary = s->h_counters[2];
         s->last.node_tests_shadow = s->h_counters[3];

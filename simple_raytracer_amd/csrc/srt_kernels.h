@@ -1,0 +1,577 @@
+// srt_kernels.h -- the HIP kernels of the ray-trace path (gfx950).  Included by srt_hip.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "srt_device.h"
+
+using namespace srt;
+
+// =================================================================================================
+// Device-side scene / params views (passed by value in kernarg SGPRs)
+// =================================================================================================
+struct DevScene {
+    const DevNode* nodes;
+    const DevTri* tris;
+    const int32_t* tri_obj;
+    const int32_t* tri_tex;       // may be null (no textures)
+    const float* tri_tc;          // n_tris x 6, may be null
+    const float* obj_color;       // n_objects x 3
+    const float* obj_mat;         // n_objects x 3
+    const int2* obj_range;        // n_objects: [first node, end node) in pre-order
+    const uint8_t* tex;
+    const unsigned long long* tex_off;
+    const uint32_t* tex_w;
+    const uint32_t* tex_h;
+    const unsigned long long* tex_size;
+    uint32_t n_nodes, n_tris, n_objects;
+};
+
+struct DevParams {
+    uint32_t W, H, rows;
+    uint32_t block_rows, block_first, block_stride;
+    int32_t i0, j0;
+    float focal;
+    uint32_t n_lights;
+    const float* lights;          // device, n_lights x 3
+    float shadow_div, reinhard, gamma;
+    uint32_t bg;                  // r | g << 8 | b << 16
+};
+
+// counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
+__device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// Hit-pixel statistic without a hot atomic: one word takes ~12 ns per atomic, so 32 k waves adding to one
+// address would serialise for ~0.4 ms.  64 shards, 64 B apart, summed on the host.
+constexpr int HIT_SHARDS = 64;
+constexpr int CTR_HIT_BASE = 8;                  // counters[8 + 8*shard]
+__device__ __forceinline__ void count_hits(unsigned long long* counters, bool is_hit) {
+    const unsigned long long m = __ballot(is_hit);
+    if ((threadIdx.x & 63) == 0 && m) {
+        const uint32_t shard = (blockIdx.y * gridDim.x + blockIdx.x) & (HIT_SHARDS - 1);
+        atomicAdd(counters + CTR_HIT_BASE + 8 * shard, (unsigned long long)__popcll(m));
+    }
+}
+
+// 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
+// a wave are neighbours, so they walk the same top-of-tree nodes (loads of one node by many lanes
+// coalesce into one 32 B fetch) and diverge only deep in the tree.
+__device__ __forceinline__ bool tile_pixel(const DevParams& p, uint32_t& px, uint32_t& r) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    r  = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    return px < p.W && r < p.rows;
+}
+// local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
+__device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
+    return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
+}
+// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
+__device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
+    return mk((float)(p.i0 + (int)px) + 0.0f, (float)(p.j0 + (int)y) + 0.0f, p.focal);
+}
+
+// =================================================================================================
+// Kernel 1: closest hit.  rayIntersection:405-431 with boundingBoxIntersection:296-317 fused in:
+// walk ALL slab-passing nodes of ALL objects in pre-order (== reference visit order), test leaf
+// triangles in stored order, strict '<' keeps the first (lowest id) of equal t.  No t-pruning: the
+// reference has none and its slab test may cull what Moller-Trumbore would hit, so the candidate
+// set must be reproduced exactly.
+// =================================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_closest_hit(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+                                                     float* __restrict__ t_out, unsigned long long* __restrict__ counters) {
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    unsigned long long n_node = 0, n_tri = 0;
+    float best = __builtin_inff();
+    int32_t best_id = -1;
+    if (live) {
+        const V3 o = mk(0.0f, 0.0f, 0.0f);
+        const V3 d = primary_dir(p, px, image_row(p, r));
+        const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+        const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+        int32_t i = 0;
+        const int32_t n = (int32_t)s.n_nodes;
+        while (i < n) {
+            const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+            const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+            if (COUNT) n_node++;
+            if (ray_aabb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                if (leaf >= 0) {
+                    const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
+                    for (int32_t k = 0; k < cnt; k++) {
+                        const size_t ti = (size_t)(first + k) * 3;
+                        const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                        const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                        if (COUNT) n_tri++;
+                        const float t = ray_triangle(o, d, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                        if (t != SRT_NEG_INF && t < best) { best = t; best_id = first + k; }
+                    }
+                }
+                i = i + 1;
+            } else {
+                i = skip;
+            }
+        }
+        const size_t pix = (size_t)r * p.W + px;
+        hit_id[pix] = best_id;
+        t_out[pix] = best;
+    }
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
+// Kernel 1, wave-queue form.  Same traversal, but the Moller-Trumbore tests are taken out of the
+// divergent per-lane loop: a lane that passes a leaf's box pushes (triangle, lane) pairs into a
+// per-wavefront LDS queue; whenever 64 pairs are queued the whole wave tests them at once (one pair per
+// lane, 100 % SIMD utilisation) and merges with a 64-bit LDS atomicMin on (t bits << 32 | triangle id).
+// t >= 0 orders as its bit pattern, so the minimum key is the reference's closest hit and, on equal t,
+// the lowest id, i.e. the first in visit order (strict '<', simple_raytracer.cpp:429).
+// =================================================================================================
+constexpr int QCAP = 64 + 64 * 8 + 64;      // leftover (< 64) + one push round (64 lanes x <= 8) + slack
+constexpr int PUSH_MAX = 8;                 // per lane per round; larger leaves are pushed in slices
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <bool COUNT, bool PREFETCH>
+__global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+                                                       float* __restrict__ t_out, float* __restrict__ rgb_linear,
+                                                       uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t q_all[4][QCAP];
+    __shared__ unsigned long long best_all[256];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* q = q_all[wave];
+    unsigned long long* best = best_all + wave * 64;
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    const uint32_t tile_x = blockIdx.x * 16 + (wave & 1) * 8, tile_r = blockIdx.y * 16 + (wave >> 1) * 8;
+    unsigned long long n_node = 0, n_tri = 0;
+    best[lane] = ~0ull;
+    const V3 o = mk(0.0f, 0.0f, 0.0f);
+    const V3 d = primary_dir(p, px, image_row(p, live ? r : 0));
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    const int32_t n = (int32_t)s.n_nodes;
+    int32_t i = live ? 0 : n;
+    int32_t leaf_off = 0;
+    uint32_t qn = 0;                                    // wave-uniform queue length
+    float4 na = nodes4[0], nb = nodes4[1];              // node i (valid while i < n)
+    for (;;) {
+        const bool active = i < n;
+        const unsigned long long act = __ballot(active);
+        if (act) {
+            uint32_t cnt = 0, first = 0;
+            if (active) {
+                const float4 a = na, b = nb;
+                const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+                float4 pa, pb;
+                if (PREFETCH) {                          // node i+1 is the successor whenever the test passes
+                    const int32_t j = (i + 1 < n) ? i + 1 : i;
+                    pa = nodes4[2 * (size_t)j]; pb = nodes4[2 * (size_t)j + 1];
+                }
+                if (COUNT && leaf_off == 0) n_node++;
+                int32_t next;
+                bool stay = false;
+                if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                    next = i + 1;
+                    if (leaf >= 0) {
+                        const int32_t c = (leaf & LEAF_MAX) - leaf_off;
+                        first = (uint32_t)((leaf >> LEAF_SHIFT) + leaf_off);
+                        cnt = (uint32_t)(c < PUSH_MAX ? c : PUSH_MAX);
+                        if (c > PUSH_MAX) { leaf_off += PUSH_MAX; stay = true; } else leaf_off = 0;
+                    }
+                } else {
+                    next = skip;
+                }
+                if (!stay) {
+                    if (PREFETCH && next == i + 1) { na = pa; nb = pb; }
+                    else if (next < n) { na = nodes4[2 * (size_t)next]; nb = nodes4[2 * (size_t)next + 1]; }
+                    i = next;
+                }
+            }
+            // wave-wide exclusive prefix sum of cnt (0..8) by bit planes
+            uint32_t pre = 0, tot = 0;
+            #pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                const unsigned long long m = __ballot((cnt >> bit) & 1u);
+                pre += lane_prefix(m) << bit;
+                tot += (uint32_t)__popcll(m) << bit;
+            }
+            for (uint32_t k = 0; k < cnt; k++) q[qn + pre + k] = ((first + k) << 6) | lane;
+            qn += tot;
+        } else if (qn == 0) {
+            break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 64 || (!act && qn)) {
+            const uint32_t m = qn < 64 ? qn : 64;
+            qn -= m;
+            if (lane < m) {
+                const uint32_t e = q[qn + lane];
+                const uint32_t src = e & 63u, tri = e >> 6;
+                const V3 ds = primary_dir(p, tile_x + (src & 7), image_row(p, tile_r + (src >> 3)));
+                const size_t ti = (size_t)tri * 3;
+                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                if (COUNT) n_tri++;
+                const float t = ray_triangle(o, ds, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                // candidate iff t != -inf && t < +inf (the initial distanceComparison, :408); NaN fails '<'
+                if (t != SRT_NEG_INF && t < __builtin_inff()) {
+                    const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);     // -0.0 ties with +0.0
+                    atomicMin(&best[src], ((unsigned long long)tb << 32) | tri);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool is_hit = false;
+    if (live) {
+        const unsigned long long key = best[lane];
+        int32_t id = -1;
+        float t = __builtin_inff();
+        if (key != ~0ull) {
+            id = (int32_t)(uint32_t)key;
+            // the winner's t with its own bits (incl. the sign of a zero): same function, same inputs
+            const size_t ti = (size_t)id * 3;
+            const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+            const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+            t = ray_triangle(o, d, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+        }
+        const size_t pix = (size_t)r * p.W + px;
+        hit_id[pix] = id;
+        t_out[pix] = t;
+        if (id < 0) {      // a miss is final here: zero light sum, background pixel (:518, drawImage:476-487)
+            if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+            if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+        }
+        is_hit = id >= 0;
+    }
+    count_hits(counters, is_hit);
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
+// Kernel 2: shadow rays + shading + tone map.  softShadow:348-401 -> shadowIntersection:321-342 +
+// phongIllumination:144-200, then the quantiser (:447-449) and the black -> background rule
+// (:518, drawImage:476-487).  Shading runs once, for the closest hit (the reference re-shades every
+// improving hit and keeps the last: same value).  The hit object's own tree is skipped (the reference
+// walks it and discards the result, :328/:331) and the any-hit walk exits at the first hit.
+// =================================================================================================
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit_range(const DevScene& s, int2 self, V3 so, V3 sd,
+                                              unsigned long long& n_node, unsigned long long& n_tri) {
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    int32_t i = 0;
+    const int32_t n = (int32_t)s.n_nodes;
+    while (i < n) {
+        if (i == self.x) { i = self.y; continue; }
+        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+        const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+        if (COUNT) n_node++;
+        if (ray_aabb(so, sd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+            if (leaf >= 0) {
+                const int32_t first = leaf >> LEAF_SHIFT, cnt = leaf & LEAF_MAX;
+                for (int32_t k = 0; k < cnt; k++) {
+                    const size_t ti = (size_t)(first + k) * 3;
+                    const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                    const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                    if (COUNT) n_tri++;
+                    const float t = ray_triangle(so, sd, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                    if (t != SRT_NEG_INF) return true;       // any t >= 0, NaN included (:335)
+                }
+            }
+            i = i + 1;
+        } else {
+            i = skip;
+        }
+    }
+    return false;
+}
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit(const DevScene& s, int32_t self_obj, V3 so, V3 sd,
+                                        unsigned long long& n_node, unsigned long long& n_tri) {
+    return any_hit_range<COUNT>(s, s.obj_range[self_obj], so, sd, n_node, n_tri);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                               const float* __restrict__ t_in, float* __restrict__ rgb_linear,
+                                               uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    unsigned long long n_node = 0, n_tri = 0;
+    bool is_hit = false;
+    if (live) {
+        const size_t pix = (size_t)r * p.W + px;
+        const int32_t id = hit_id[pix];
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        int q0 = 0, q1 = 0, q2 = 0;
+        if (id >= 0) {
+            is_hit = true;
+            const float t = t_in[pix];
+            const V3 o = mk(0.0f, 0.0f, 0.0f);
+            const V3 d = primary_dir(p, px, image_row(p, r));
+            const int32_t obj = s.tri_obj[id];
+            const float4* tp = reinterpret_cast<const float4*>(s.tris) + (size_t)id * 3;
+            const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const V3 nrm = mk(t2.y, t2.z, t2.w);
+            V3 color = mk(s.obj_color[obj * 3], s.obj_color[obj * 3 + 1], s.obj_color[obj * 3 + 2]);     // :437-440
+            const int32_t tex = s.tri_tex ? s.tri_tex[id] : -1;
+            if (tex >= 0) {                                                                             // :350-361
+                const V3 P = o + d * t;
+                const V3 bc = barycentric(mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, t2.x), P);
+                const float* tc = s.tri_tc + (size_t)id * 6;
+                const float tx = (bc.x * tc[0] + bc.y * tc[2]) + bc.z * tc[4];                          // :123-125
+                const float ty = (bc.x * tc[1] + bc.y * tc[3]) + bc.z * tc[5];
+                long long idx = ((long long)((int)ty * (int)s.tex_w[tex] + (int)tx)) * 3;               // :357
+                // the reference reads out of bounds here if the texel index leaves the image (UB);
+                // this kernel clamps into the texture instead of faulting
+                const long long last = (long long)s.tex_size[tex] - 3;
+                idx = idx < 0 ? 0 : (idx > last ? last : idx);
+                const uint8_t* td = s.tex + s.tex_off[tex] + idx;
+                color = mk(td[0] / 255.0f, td[1] / 255.0f, td[2] / 255.0f);
+            }
+            const float ka = s.obj_mat[obj * 3], ks = s.obj_mat[obj * 3 + 1], sh = s.obj_mat[obj * 3 + 2];
+            const V3 dt = d * t;                      // shadowIntersection:325-326: origin d*t, dir L - d*t
+            for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
+                const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
+                const bool shadowed = any_hit<COUNT>(s, obj, dt, L - dt, n_node, n_tri);
+                V3 c = phong(nrm, o, d, L, color, ka, ks, sh, t);
+                if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
+                sum = sum + c;                                                                          // :370
+            }
+            q0 = quant1(tone1(sum.x, p.reinhard, p.gamma));                                             // :391-398,447-449
+            q1 = quant1(tone1(sum.y, p.reinhard, p.gamma));
+            q2 = quant1(tone1(sum.z, p.reinhard, p.gamma));
+        }
+        if (rgb_linear) { rgb_linear[pix * 3] = sum.x; rgb_linear[pix * 3 + 1] = sum.y; rgb_linear[pix * 3 + 2] = sum.z; }
+        if (rgb8) {
+            if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
+            rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
+        }
+    }
+    count_hits(counters, is_hit);
+    if (COUNT) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
+}
+
+
+// =================================================================================================
+// Kernel 2a: shadow rays, one wavefront per 8x8 pixel tile (same tiles as the closest-hit kernel).
+// The wave compacts its hit pixels (ballot + rank), then walks work items (hit pixel, light sample)
+// 64 at a time, so lanes are full whatever the hit pattern and, for many light samples, the 64 rays of
+// a step share their origin.  shadowIntersection:321-342: origin d*t, direction L - d*t (unnormalised,
+// no epsilon); any candidate of ANOTHER object with Moller-Trumbore != -inf (NaN included) shadows.
+// Same wave-queue scheme as the closest-hit kernel; a hit raises the ray's flag and the ray stops.
+// Result: per tile and light sample one 64-bit word, bit = pixel lane.
+// SEQ = true is the counting build: per-lane sequential walk with exit at the first hit, whose slab /
+// triangle test counts are the algorithmic counts the CPU oracle mirrors.
+// =================================================================================================
+template <bool SEQ>
+__global__ __launch_bounds__(256) void k_shadow(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                                const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
+                                                unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t q_all[4][QCAP];
+    __shared__ float4 ray_all[4][128];
+    __shared__ uint32_t flag_all[256];
+    __shared__ float4 pix_all[4][64];              // per hit rank: t, pixel lane, own object's node range
+    __shared__ unsigned long long bits_all[4][64];  // per light of the current group: shadowed pixel lanes
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* q = q_all[wave];
+    float4* ray = ray_all[wave];
+    uint32_t* flag = flag_all + wave * 64;
+    float4* pixd = pix_all[wave];
+    unsigned long long* bits = bits_all[wave];
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    const int32_t n = (int32_t)s.n_nodes;
+    uint32_t px, r;
+    const bool live = tile_pixel(p, px, r);
+    const uint32_t tile_x = blockIdx.x * 16 + (wave & 1) * 8, tile_r = blockIdx.y * 16 + (wave >> 1) * 8;
+    const size_t tile_index = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    unsigned long long n_node = 0, n_tri = 0;
+    int32_t id = -1;
+    if (live) id = hit_id[(size_t)r * p.W + px];
+    const unsigned long long hm = __ballot(id >= 0);
+    if (hm == 0) return;                             // wave-uniform: no hit pixel in this tile
+    const uint32_t nh = (uint32_t)__popcll(hm);
+    if (id >= 0) {
+        const int2 self = s.obj_range[s.tri_obj[id]];
+        pixd[lane_prefix(hm)] = make_float4(t_in[(size_t)r * p.W + px], __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {           // light samples in groups of 64
+        const uint32_t Lg = (p.n_lights - l0) < 64u ? (p.n_lights - l0) : 64u;
+        bits[lane] = 0ull;
+        const uint32_t n_items = nh * Lg;
+        for (uint32_t base = 0; base < n_items; base += 64) {
+            const uint32_t item = base + lane;
+            const bool valid = item < n_items;
+            V3 so = mk(0.f, 0.f, 0.f), sd = mk(0.f, 0.f, 1.f);
+            int2 self = make_int2(-1, -1);
+            uint32_t pl = 0, lg = 0;
+            if (valid) {
+                const uint32_t hr = item / Lg;
+                lg = item - hr * Lg;
+                const float4 pd = pixd[hr];
+                pl = __float_as_uint(pd.y);
+                self = make_int2(__float_as_int(pd.z), __float_as_int(pd.w));
+                const V3 d = primary_dir(p, tile_x + (pl & 7), image_row(p, tile_r + (pl >> 3)));
+                const uint32_t l = l0 + lg;
+                const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
+                so = d * pd.x;                            // :326
+                sd = L - so;                              // :325
+            }
+            bool shadowed = false;
+            if (SEQ) {
+                if (valid) shadowed = any_hit_range<true>(s, self, so, sd, n_node, n_tri);
+            } else {
+                ray[lane] = make_float4(so.x, so.y, so.z, 0.f);
+                ray[64 + lane] = make_float4(sd.x, sd.y, sd.z, 0.f);
+                flag[lane] = 0u;
+                int32_t i = valid ? 0 : n;
+                if (i == self.x) i = self.y;
+                int32_t leaf_off = 0;
+                uint32_t qn = 0;
+                float4 na = nodes4[0], nb = nodes4[1];
+                if (i < n) { na = nodes4[2 * (size_t)i]; nb = nodes4[2 * (size_t)i + 1]; }
+                __builtin_amdgcn_wave_barrier();
+                for (;;) {
+                    if (flag[lane]) i = n;                // already shadowed: stop walking
+                    const bool active = i < n;
+                    const unsigned long long act = __ballot(active);
+                    if (act) {
+                        uint32_t cnt = 0, first = 0;
+                        if (active) {
+                            const float4 a = na, b = nb;
+                            const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
+                            int32_t next;
+                            bool stay = false;
+                            if (ray_aabb_nb(so, sd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                next = i + 1;
+                                if (leaf >= 0) {
+                                    const int32_t c = (leaf & LEAF_MAX) - leaf_off;
+                                    first = (uint32_t)((leaf >> LEAF_SHIFT) + leaf_off);
+                                    cnt = (uint32_t)(c < PUSH_MAX ? c : PUSH_MAX);
+                                    if (c > PUSH_MAX) { leaf_off += PUSH_MAX; stay = true; } else leaf_off = 0;
+                                }
+                            } else {
+                                next = skip;
+                            }
+                            if (!stay) {
+                                if (next == self.x) next = self.y;        // never enter the hit object's own tree (:331)
+                                if (next < n) { na = nodes4[2 * (size_t)next]; nb = nodes4[2 * (size_t)next + 1]; }
+                                i = next;
+                            }
+                        }
+                        uint32_t pre = 0, tot = 0;
+                        #pragma unroll
+                        for (int bit = 0; bit < 4; bit++) {
+                            const unsigned long long m = __ballot((cnt >> bit) & 1u);
+                            pre += lane_prefix(m) << bit;
+                            tot += (uint32_t)__popcll(m) << bit;
+                        }
+                        for (uint32_t k = 0; k < cnt; k++) q[qn + pre + k] = ((first + k) << 6) | lane;
+                        qn += tot;
+                    } else if (qn == 0) {
+                        break;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    while (qn >= 64 || (!act && qn)) {
+                        const uint32_t m = qn < 64 ? qn : 64;
+                        qn -= m;
+                        if (lane < m) {
+                            const uint32_t e = q[qn + lane];
+                            const uint32_t src = e & 63u, tri = e >> 6;
+                            if (!flag[src]) {
+                                const float4 ro = ray[src], rd = ray[64 + src];
+                                const size_t ti = (size_t)tri * 3;
+                                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                                const float t = ray_triangle(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), mk(t0.x, t0.y, t0.z),
+                                                             mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                                if (t != SRT_NEG_INF) flag[src] = 1u;     // any t >= 0, NaN included (:335)
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                shadowed = flag[lane] != 0u;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (shadowed && valid) atomicOr(&bits[lg], 1ull << pl);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < Lg) shadow_bits[tile_index * p.n_lights + l0 + lane] = bits[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
+}
+
+// =================================================================================================
+// Kernel 2b: shading, one thread per hit pixel (same tiles).  softShadow:348-401 (texture fetch,
+// light-sample loop with in-order f32 sum, /5 for shadowed samples, Reinhard + gamma),
+// phongIllumination:144-200, quantiser :447-449, black -> background (:518, drawImage:476-487).
+// Pure ALU, no traversal; misses were finished by the closest-hit kernel.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                                    const float* __restrict__ t_in,
+                                                    const unsigned long long* __restrict__ shadow_bits,
+                                                    float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t px, r;
+    if (!tile_pixel(p, px, r)) return;
+    const size_t pix = (size_t)r * p.W + px;
+    const int32_t id = hit_id[pix];
+    if (id < 0) return;
+    const size_t tile_index = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    const float t = t_in[pix];
+    const V3 o = mk(0.0f, 0.0f, 0.0f);
+    const V3 d = primary_dir(p, px, image_row(p, r));
+    const int32_t obj = s.tri_obj[id];
+    const float4* tp = reinterpret_cast<const float4*>(s.tris) + (size_t)id * 3;
+    const float4 t2 = tp[2];
+    const V3 nrm = mk(t2.y, t2.z, t2.w);
+    V3 color = mk(s.obj_color[obj * 3], s.obj_color[obj * 3 + 1], s.obj_color[obj * 3 + 2]);     // :437-440
+    const int32_t tex = s.tri_tex ? s.tri_tex[id] : -1;
+    if (tex >= 0) {                                                                             // :350-361
+        const float4 t0 = tp[0], t1 = tp[1];
+        const V3 P = o + d * t;
+        const V3 bc = barycentric(mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, t2.x), P);
+        const float* tc = s.tri_tc + (size_t)id * 6;
+        const float tx = (bc.x * tc[0] + bc.y * tc[2]) + bc.z * tc[4];                          // :123-125
+        const float ty = (bc.x * tc[1] + bc.y * tc[3]) + bc.z * tc[5];
+        long long idx = ((long long)((int)ty * (int)s.tex_w[tex] + (int)tx)) * 3;               // :357
+        // the reference reads out of bounds if the texel index leaves the image (UB); clamp instead
+        const long long last = (long long)s.tex_size[tex] - 3;
+        idx = idx < 0 ? 0 : (idx > last ? last : idx);
+        const uint8_t* td = s.tex + s.tex_off[tex] + idx;
+        color = mk(td[0] / 255.0f, td[1] / 255.0f, td[2] / 255.0f);
+    }
+    const float ka = s.obj_mat[obj * 3], ks = s.obj_mat[obj * 3 + 1], sh = s.obj_mat[obj * 3 + 2];
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    const unsigned long long* sb = shadow_bits + tile_index * p.n_lights;
+    for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
+        const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
+        const bool shadowed = (sb[l] >> lane) & 1ull;
+        V3 c = phong(nrm, o, d, L, color, ka, ks, sh, t);
+        if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
+        sum = sum + c;                                                                          // :370
+    }
+    int q0 = quant1(tone1(sum.x, p.reinhard, p.gamma));                                         // :391-398,447-449
+    int q1 = quant1(tone1(sum.y, p.reinhard, p.gamma));
+    int q2 = quant1(tone1(sum.z, p.reinhard, p.gamma));
+    if (rgb_linear) { rgb_linear[pix * 3] = sum.x; rgb_linear[pix * 3 + 1] = sum.y; rgb_linear[pix * 3 + 2] = sum.z; }
+    if (rgb8) {
+        if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
+        rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
+    }
+}

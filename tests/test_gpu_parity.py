@@ -146,3 +146,49 @@ def test_dropin_entry_point_matches_reference_image(srt):
         check_rgb8(q.astype(np.uint8), g.out(W, H, 1, "rgb8"))
         want = g.out(W, H, 1, "rgb8")
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
+
+
+@pytest.mark.parametrize("variant", [1])
+@pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
+                                        ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
+def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
+    """Experimental closest-hit kernel variants (srt_params.flags bits 8-15; 0 = shipped default) produce
+    the same hits, t bits and work counts."""
+    g, ds = device_scene(srt, name)
+    p = g.params(W, H, L, flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
+    o = ds.render(p)
+    assert np.array_equal(o["hit_id"], g.out(W, H, L, "hit_id"))
+    assert gu.sha(o["t"]) == str(g.out(W, H, L, "sha_t"))
+    c = oracle.render(g.flat, g.params(W, H, L))
+    assert o["stats"]["node_tests_primary"] == c["stats"]["node_tests_primary"]
+    assert o["stats"]["tri_tests_primary"] == c["stats"]["tri_tests_primary"]
+    assert o["stats"]["node_tests_shadow"] == c["stats"]["node_tests_shadow"]
+    assert o["stats"]["tri_tests_shadow"] == c["stats"]["tri_tests_shadow"]
+    d = ds.render(g.params(W, H, L))                      # shipped pipeline, non-counting build
+    assert np.array_equal(d["hit_id"], o["hit_id"]) and np.array_equal(bits(d["t"]), bits(o["t"]))
+    assert np.array_equal(bits(d["rgb_linear"]), bits(o["rgb_linear"])) and np.array_equal(d["rgb8"], o["rgb8"])
+
+
+def test_big_leaves_and_signed_zero_t(srt, oracle):
+    """Leaves larger than one push round (the ABI allows up to 31 triangles per leaf) and a triangle plane
+    through the camera origin (t = +-0 ties) behave as in the oracle."""
+    rng = np.random.default_rng(5)
+    n = 27
+    pts = np.ones((n, 3, 4), np.float32)
+    c = rng.uniform(-40, 40, (n, 1, 3)).astype(np.float32); c[..., 2] += 300
+    pts[..., :3] = c + rng.uniform(-60, 60, (n, 3, 3)).astype(np.float32)
+    # two coplanar triangles whose plane contains the origin's ray set: z-x plane through y = 0
+    pts[0, :, :3] = [[-50, 0, 100], [50, 0, 100], [0, 0, 900]]
+    pts[1, :, :3] = [[-80, 0, 50], [80, 0, 50], [0, 0, -40]]
+    mn = pts[..., :3].reshape(-1, 3).min(0); mx = pts[..., :3].reshape(-1, 3).max(0)
+    flat = abi.FlatScene(node_min=np.stack([mn, mn, mn]), node_max=np.stack([mx, mx, mx]),
+                         node_left=[1, -1, -1], node_right=[2, -1, -1], node_first=[-1, 0, n], node_count=[0, n, 0],
+                         obj_root=[0], tri_points=pts, tri_obj=np.zeros(n, np.int32),
+                         obj_color=[[0.8, 0.6, 0.2]], obj_material=[[0.2, 0.5, 15.0]])
+    ds = srt.DeviceScene(flat)
+    for variant in (0, 1):
+        p = abi.make_params(96, 64, [[100.0, -200.0, 50.0]], flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
+        o = ds.render(p); c = oracle.render(flat, p)
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+        assert o["stats"]["tri_tests_primary"] == c["stats"]["tri_tests_primary"]
+    assert (c["t"] == 0).any(), "test scene should contain t == 0 hits"
