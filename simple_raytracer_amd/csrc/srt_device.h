@@ -19,7 +19,7 @@ struct __attribute__((aligned(16))) DevNode {
     float minx, miny, minz, maxx;
     float maxy, maxz;
     int32_t skip;      // index of the first node after this node's subtree
-    int32_t leaf;      // -1 inner; else (first_triangle << 5) | count
+    int32_t leaf;      // inner: ~(index of the right child) < 0 (the left child is i+1); leaf: (first_triangle << 5) | count
 };
 static_assert(sizeof(DevNode) == 32, "node record is 32 B");
 

@@ -199,6 +199,7 @@ static int build_device_records(const srt_scene_desc* d, std::vector<DevNode>& n
             } else if (it.state == 1) {
                 it.state = 2;
                 const int32_t r = d->node_right[it.orig];
+                nodes[it.emitted].leaf = ~(int32_t)nodes.size();     // inner node: ~(pre-order index of the right child) < 0
                 st.push_back({ r, -1, 0 });
             } else {
                 nodes[it.emitted].skip = (int32_t)nodes.size();
@@ -343,7 +344,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
     const uint32_t variant = (p->flags >> 8) & 0xffu;      // experimental kernel selector (0 = shipped pipeline)
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
-    const size_t shadow_words = (size_t)grid.x * grid.y * 4 * (p->n_lights ? p->n_lights : 1);
+    const size_t shadow_words = (size_t)((p->width + 7) / 8) * ((rows + 7) / 8) * (p->n_lights ? p->n_lights : 1);
     if (variant != 1 && s->ws_shadow_words < shadow_words) {
         if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
         if (s->ws_shadow) (void)hipFree(s->ws_shadow);
@@ -363,13 +364,25 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
         HIP_TRY(hipGetLastError());
     } else {
-        if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
-        else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);      // node-queue kernel: 4x4 pixels per wave, 8x8 per workgroup
+        #define LAUNCH_NQ(CAP) do { \
+            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters); \
+            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters); } while (0)
+        if (variant == 2) {            // one ray per lane + triangle queue
+            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        } else if (variant == 3) {     // tiny node queue: exercises the stackless overflow path
+            LAUNCH_NQ(160);
+        } else {
+            LAUNCH_NQ(1024);
+        }
+        #undef LAUNCH_NQ
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], stream));
         if (p->n_lights) {
-            if (count) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
-            else       hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev[2], stream));

@@ -258,6 +258,191 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
 }
 
 // =================================================================================================
+// Kernel 1, node-queue form (shipped).  Lanes are decoupled from pixels: a wavefront owns a 4x4 pixel
+// tile and keeps TWO LDS queues -- (node, pixel) pairs still to be slab-tested and (triangle, pixel)
+// pairs still to be Moller-Trumbore-tested.  Every step pops 64 node pairs (LIFO, so the frontier stays
+// depth-first small), tests them one per lane, pushes both children of a passing inner node and the
+// triangles of a passing leaf.  All 64 lanes work as long as the tile has work, whatever the spread
+// between its rays, and a heavy tile's work is cut into 4x more (and 4x shorter) waves than with one
+// ray per lane.  The set of tested pairs is exactly "every node whose ancestors all pass"
+// (boundingBoxIntersection:296-317) and the merge is the order-independent (t, id) minimum, so hits,
+// t bits and work counts are those of the reference walk.
+// If the node queue cannot take a step's children the wave finishes those subtrees with the stackless
+// pre-order walk (skip links) instead -- any tree shape is handled with bounded LDS.
+// =================================================================================================
+constexpr int NQ_P = 16;                    // pixels per wavefront (4x4)
+
+template <bool COUNT, int NQCAP>
+__global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+                                                        float* __restrict__ t_out, float* __restrict__ rgb_linear,
+                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ unsigned long long best_all[4][NQ_P];
+    __shared__ float2 dir_all[4][NQ_P];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* nq = nq_all[wave];
+    uint32_t* tq = tq_all[wave];
+    unsigned long long* best = best_all[wave];
+    float2* dir = dir_all[wave];
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    const uint32_t tile_x = blockIdx.x * 8 + (wave & 1) * 4, tile_r = blockIdx.y * 8 + (wave >> 1) * 4;
+    const uint32_t px = tile_x + (lane & 3), r = tile_r + ((lane >> 2) & 3);
+    const bool live = lane < NQ_P && px < p.W && r < p.rows;
+    const V3 o = mk(0.0f, 0.0f, 0.0f);
+    V3 dmine = mk(0.f, 0.f, p.focal);
+    if (lane < NQ_P) {
+        best[lane] = ~0ull;
+        if (live) dmine = primary_dir(p, px, image_row(p, r));
+        dir[lane] = make_float2(dmine.x, dmine.y);
+    }
+    const uint32_t livem = (uint32_t)__ballot(live);
+    unsigned long long n_node = 0, n_tri = 0;
+    uint32_t nqn = 0, tqn = 0;                       // wave-uniform queue lengths
+    __builtin_amdgcn_wave_barrier();
+
+    // one batch of <= 64 queued (triangle, pixel) pairs, one per lane
+    auto tri_batch = [&]() {
+        const uint32_t m = tqn < 64 ? tqn : 64;
+        tqn -= m;
+        if (lane < m) {
+            const uint32_t e = tq[tqn + lane];
+            const uint32_t pl = e & 63u, tri = e >> 6;
+            const float2 dxy = dir[pl];
+            const size_t ti = (size_t)tri * 3;
+            const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+            const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+            if (COUNT) n_tri++;
+            const float t = ray_triangle(o, mk(dxy.x, dxy.y, p.focal), mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+            // candidate iff t != -inf && t < +inf (the initial distanceComparison, :408); NaN fails '<'
+            if (t != SRT_NEG_INF && t < __builtin_inff()) {
+                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);     // -0.0 ties with +0.0
+                atomicMin(&best[pl], ((unsigned long long)tb << 32) | tri);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // queue the triangles [first, first+cnt) of each lane's passing leaf (cnt = 0: nothing), <= 8 per lane per round
+    auto push_tris = [&](uint32_t first, uint32_t cnt, uint32_t pl) {
+        uint32_t off = 0;
+        while (__ballot(off < cnt)) {
+            const uint32_t c = off < cnt ? ((cnt - off) < (uint32_t)PUSH_MAX ? (cnt - off) : (uint32_t)PUSH_MAX) : 0u;
+            uint32_t pre = 0, tot = 0;
+            #pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                const unsigned long long m = __ballot((c >> bit) & 1u);
+                pre += lane_prefix(m) << bit;
+                tot += (uint32_t)__popcll(m) << bit;
+            }
+            for (uint32_t k = 0; k < c; k++) tq[tqn + pre + k] = ((first + off + k) << 6) | pl;
+            tqn += tot;
+            off += PUSH_MAX;
+            __builtin_amdgcn_wave_barrier();
+            while (tqn >= 64) tri_batch();
+        }
+    };
+
+    const uint32_t n_obj = s.n_objects;
+    const uint32_t nlive = (uint32_t)__popc(livem);
+    constexpr uint32_t OBJ_G = (NQCAP / 32) < 16 ? (NQCAP / 32) : 16;      // roots pushed at once: 16 * OBJ_G <= NQCAP / 2
+    for (uint32_t obj0 = 0; obj0 < n_obj && nlive; obj0 += OBJ_G) {
+        // roots of up to OBJ_G objects for every live pixel, in chunks of 64 (node, pixel) pairs
+        const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
+        for (uint32_t base = 0; base < NQ_P * g; base += 64) {
+            const uint32_t k = base + lane;
+            const uint32_t pl = k & (NQ_P - 1), ob = k >> 4;
+            const bool ok = k < NQ_P * g && ((livem >> pl) & 1u);
+            const unsigned long long m = __ballot(ok);
+            if (ok) nq[nqn + lane_prefix(m)] = ((uint32_t)s.obj_range[obj0 + ob].x << 6) | pl;
+            nqn += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (nqn) {
+            const uint32_t m = nqn < 64 ? nqn : 64;
+            nqn -= m;
+            const bool have = lane < m;
+            uint32_t pl = 0, cnt = 0, first = 0;
+            int32_t node = 0, info = -1, skip = 0;
+            bool inner = false;
+            V3 d = mk(0.f, 0.f, p.focal);
+            if (have) {
+                const uint32_t e = nq[nqn + lane];
+                pl = e & 63u; node = (int32_t)(e >> 6);
+                const float4 a = nodes4[2 * (size_t)node], b = nodes4[2 * (size_t)node + 1];
+                const float2 dxy = dir[pl];
+                d = mk(dxy.x, dxy.y, p.focal);
+                skip = __float_as_int(b.z); info = __float_as_int(b.w);
+                if (COUNT) n_node++;
+                if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                    if (info < 0) inner = true;
+                    else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long im = __ballot(inner);
+            const uint32_t n_in = (uint32_t)__popcll(im);
+            if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
+                if (inner) {
+                    const uint32_t pos = nqn + 2 * lane_prefix(im);
+                    nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
+                    nq[pos + 1] = ((uint32_t)(node + 1) << 6) | pl;   // left child on top: popped first
+                }
+                nqn += 2 * n_in;
+                push_tris(first, cnt, pl);
+            } else {
+                // queue full: finish these subtrees with the stackless pre-order walk (i = pass ? i+1 : skip[i])
+                push_tris(first, cnt, pl);
+                int32_t i = inner ? node + 1 : 0, end = inner ? skip : 0;
+                while (__ballot(i < end)) {
+                    uint32_t c2 = 0, f2 = 0;
+                    if (i < end) {
+                        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+                        const int32_t sk = __float_as_int(b.z), inf2 = __float_as_int(b.w);
+                        if (COUNT) n_node++;
+                        if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                            if (inf2 >= 0) { c2 = (uint32_t)(inf2 & LEAF_MAX); f2 = (uint32_t)(inf2 >> LEAF_SHIFT); }
+                            i = i + 1;
+                        } else {
+                            i = sk;
+                        }
+                    }
+                    push_tris(f2, c2, pl);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    while (tqn) tri_batch();
+    __builtin_amdgcn_wave_barrier();
+
+    bool is_hit = false;
+    if (live) {
+        const unsigned long long key = best[lane];
+        int32_t id = -1;
+        float t = __builtin_inff();
+        if (key != ~0ull) {
+            id = (int32_t)(uint32_t)key;
+            // the winner's t with its own bits (incl. the sign of a zero): same function, same inputs
+            const size_t ti = (size_t)id * 3;
+            const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+            const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+            t = ray_triangle(o, dmine, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+        }
+        const size_t pix = (size_t)r * p.W + px;
+        hit_id[pix] = id;
+        t_out[pix] = t;
+        if (id < 0) {      // a miss is final here: zero light sum, background pixel (:518, drawImage:476-487)
+            if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+            if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+        }
+        is_hit = id >= 0;
+    }
+    count_hits(counters, is_hit);
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
 // Kernel 2: shadow rays + shading + tone map.  softShadow:348-401 -> shadowIntersection:321-342 +
 // phongIllumination:144-200, then the quantiser (:447-449) and the black -> background rule
 // (:518, drawImage:476-487).  Shading runs once, for the closest hit (the reference re-shades every
@@ -364,154 +549,205 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
 
 
 // =================================================================================================
-// Kernel 2a: shadow rays, one wavefront per 8x8 pixel tile (same tiles as the closest-hit kernel).
-// The wave compacts its hit pixels (ballot + rank), then walks work items (hit pixel, light sample)
-// 64 at a time, so lanes are full whatever the hit pattern and, for many light samples, the 64 rays of
-// a step share their origin.  shadowIntersection:321-342: origin d*t, direction L - d*t (unnormalised,
-// no epsilon); any candidate of ANOTHER object with Moller-Trumbore != -inf (NaN included) shadows.
-// Same wave-queue scheme as the closest-hit kernel; a hit raises the ray's flag and the ray stops.
-// Result: per tile and light sample one 64-bit word, bit = pixel lane.
-// SEQ = true is the counting build: per-lane sequential walk with exit at the first hit, whose slab /
-// triangle test counts are the algorithmic counts the CPU oracle mirrors.
+// Kernel 2a: shadow rays, node-queue form.  A 256-thread workgroup owns an 8x8 pixel tile, each of its
+// four wavefronts a 4x4 quadrant.  A wave compacts its hit pixels (ballot + rank) and walks work items
+// (hit pixel, light sample) 16 rays at a time with the same two LDS queues as the closest-hit kernel:
+// 64 lanes serve 16 rays, so lanes stay full whatever the hit pattern, and with many light samples the
+// rays of a step share their origin.  shadowIntersection:321-342: origin d*t, direction L - d*t
+// (unnormalised, no epsilon); any candidate of ANOTHER object with Moller-Trumbore != -inf (NaN included)
+// shadows.  A hit raises the ray's flag; queued pairs of a flagged ray are dropped when popped.
+// Result: per 8x8 tile and light sample one 64-bit word, bit = y*8 + x inside the tile.
+// SEQ = true is the counting build: per-ray sequential pre-order walk with exit at the first hit, whose
+// slab / triangle test counts are the algorithmic counts the CPU oracle mirrors.
 // =================================================================================================
-template <bool SEQ>
-__global__ __launch_bounds__(256) void k_shadow(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
-                                                const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
-                                                unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t q_all[4][QCAP];
-    __shared__ float4 ray_all[4][128];
-    __shared__ uint32_t flag_all[256];
-    __shared__ float4 pix_all[4][64];              // per hit rank: t, pixel lane, own object's node range
-    __shared__ unsigned long long bits_all[4][64];  // per light of the current group: shadowed pixel lanes
+template <bool SEQ, int NQCAP>
+__global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                                   const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
+                                                   unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ float4 ray_all[4][2 * NQ_P];          // per ray slot: origin, direction
+    __shared__ int2 self_all[4][NQ_P];               // per ray slot: node range of the hit object
+    __shared__ uint32_t flag_all[4][NQ_P];
+    __shared__ float4 pix_all[4][NQ_P];              // per hit rank: t, pixel lane, own object's node range
+    __shared__ unsigned long long bits[64];          // per light of the current group: shadowed pixels of the 8x8 tile
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* q = q_all[wave];
+    uint32_t* nq = nq_all[wave];
+    uint32_t* tq = tq_all[wave];
     float4* ray = ray_all[wave];
-    uint32_t* flag = flag_all + wave * 64;
+    int2* selfr = self_all[wave];
+    uint32_t* flag = flag_all[wave];
     float4* pixd = pix_all[wave];
-    unsigned long long* bits = bits_all[wave];
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
-    const int32_t n = (int32_t)s.n_nodes;
-    uint32_t px, r;
-    const bool live = tile_pixel(p, px, r);
-    const uint32_t tile_x = blockIdx.x * 16 + (wave & 1) * 8, tile_r = blockIdx.y * 16 + (wave >> 1) * 8;
-    const size_t tile_index = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    const uint32_t qx = wave & 1, qy = wave >> 1;
+    const uint32_t tile_x = blockIdx.x * 8 + qx * 4, tile_r = blockIdx.y * 8 + qy * 4;
+    const uint32_t px = tile_x + (lane & 3), r = tile_r + ((lane >> 2) & 3);
+    const bool live = lane < NQ_P && px < p.W && r < p.rows;
+    const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long n_node = 0, n_tri = 0;
     int32_t id = -1;
     if (live) id = hit_id[(size_t)r * p.W + px];
-    const unsigned long long hm = __ballot(id >= 0);
-    if (hm == 0) return;                             // wave-uniform: no hit pixel in this tile
-    const uint32_t nh = (uint32_t)__popcll(hm);
+    const uint32_t hm = (uint32_t)__ballot(id >= 0);
+    const uint32_t nh = (uint32_t)__popc(hm);
     if (id >= 0) {
         const int2 self = s.obj_range[s.tri_obj[id]];
-        pixd[lane_prefix(hm)] = make_float4(t_in[(size_t)r * p.W + px], __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
+        pixd[__popc(hm & ((1u << lane) - 1u))] = make_float4(t_in[(size_t)r * p.W + px], __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
     }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {           // light samples in groups of 64
+    uint32_t nqn = 0, tqn = 0;
+
+    auto tri_batch = [&]() {
+        const uint32_t m = tqn < 64 ? tqn : 64;
+        tqn -= m;
+        if (lane < m) {
+            const uint32_t e = tq[tqn + lane];
+            const uint32_t rs = e & 63u, tri = e >> 6;
+            if (!flag[rs]) {
+                const float4 ro = ray[rs], rd = ray[NQ_P + rs];
+                const size_t ti = (size_t)tri * 3;
+                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                const float t = ray_triangle(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+                if (t != SRT_NEG_INF) flag[rs] = 1u;             // any t >= 0, NaN included (:335)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto push_tris = [&](uint32_t first, uint32_t cnt, uint32_t rs) {
+        uint32_t off = 0;
+        while (__ballot(off < cnt)) {
+            const uint32_t c = off < cnt ? ((cnt - off) < (uint32_t)PUSH_MAX ? (cnt - off) : (uint32_t)PUSH_MAX) : 0u;
+            uint32_t pre = 0, tot = 0;
+            #pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                const unsigned long long m = __ballot((c >> bit) & 1u);
+                pre += lane_prefix(m) << bit;
+                tot += (uint32_t)__popcll(m) << bit;
+            }
+            for (uint32_t k = 0; k < c; k++) tq[tqn + pre + k] = ((first + off + k) << 6) | rs;
+            tqn += tot;
+            off += PUSH_MAX;
+            __builtin_amdgcn_wave_barrier();
+            while (tqn >= 64) tri_batch();
+        }
+    };
+
+    constexpr uint32_t OBJ_G = (NQCAP / 32) < 16 ? (NQCAP / 32) : 16;
+    const uint32_t n_obj = s.n_objects;
+    for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {               // light samples in groups of 64
         const uint32_t Lg = (p.n_lights - l0) < 64u ? (p.n_lights - l0) : 64u;
-        bits[lane] = 0ull;
+        if (threadIdx.x < 64) bits[threadIdx.x] = 0ull;
+        __syncthreads();
         const uint32_t n_items = nh * Lg;
-        for (uint32_t base = 0; base < n_items; base += 64) {
+        for (uint32_t base = 0; base < n_items; base += NQ_P) {      // 16 rays per round
             const uint32_t item = base + lane;
-            const bool valid = item < n_items;
+            const bool valid = lane < NQ_P && item < n_items;
+            uint32_t pl = 0, lg = 0;
             V3 so = mk(0.f, 0.f, 0.f), sd = mk(0.f, 0.f, 1.f);
             int2 self = make_int2(-1, -1);
-            uint32_t pl = 0, lg = 0;
             if (valid) {
                 const uint32_t hr = item / Lg;
                 lg = item - hr * Lg;
                 const float4 pd = pixd[hr];
                 pl = __float_as_uint(pd.y);
                 self = make_int2(__float_as_int(pd.z), __float_as_int(pd.w));
-                const V3 d = primary_dir(p, tile_x + (pl & 7), image_row(p, tile_r + (pl >> 3)));
+                const V3 d = primary_dir(p, tile_x + (pl & 3), image_row(p, tile_r + (pl >> 2)));
                 const uint32_t l = l0 + lg;
                 const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-                so = d * pd.x;                            // :326
-                sd = L - so;                              // :325
+                so = d * pd.x;                                    // :326
+                sd = L - so;                                      // :325
             }
             bool shadowed = false;
             if (SEQ) {
                 if (valid) shadowed = any_hit_range<true>(s, self, so, sd, n_node, n_tri);
             } else {
-                ray[lane] = make_float4(so.x, so.y, so.z, 0.f);
-                ray[64 + lane] = make_float4(sd.x, sd.y, sd.z, 0.f);
-                flag[lane] = 0u;
-                int32_t i = valid ? 0 : n;
-                if (i == self.x) i = self.y;
-                int32_t leaf_off = 0;
-                uint32_t qn = 0;
-                float4 na = nodes4[0], nb = nodes4[1];
-                if (i < n) { na = nodes4[2 * (size_t)i]; nb = nodes4[2 * (size_t)i + 1]; }
+                if (lane < NQ_P) {
+                    ray[lane] = make_float4(so.x, so.y, so.z, 0.f);
+                    ray[NQ_P + lane] = make_float4(sd.x, sd.y, sd.z, 0.f);
+                    selfr[lane] = self;
+                    flag[lane] = valid ? 0u : 1u;
+                }
+                const uint32_t validm = (uint32_t)__ballot(valid);
                 __builtin_amdgcn_wave_barrier();
-                for (;;) {
-                    if (flag[lane]) i = n;                // already shadowed: stop walking
-                    const bool active = i < n;
-                    const unsigned long long act = __ballot(active);
-                    if (act) {
-                        uint32_t cnt = 0, first = 0;
-                        if (active) {
-                            const float4 a = na, b = nb;
-                            const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
-                            int32_t next;
-                            bool stay = false;
-                            if (ray_aabb_nb(so, sd, a.x, a.y, a.z, a.w, b.x, b.y)) {
-                                next = i + 1;
-                                if (leaf >= 0) {
-                                    const int32_t c = (leaf & LEAF_MAX) - leaf_off;
-                                    first = (uint32_t)((leaf >> LEAF_SHIFT) + leaf_off);
-                                    cnt = (uint32_t)(c < PUSH_MAX ? c : PUSH_MAX);
-                                    if (c > PUSH_MAX) { leaf_off += PUSH_MAX; stay = true; } else leaf_off = 0;
-                                }
-                            } else {
-                                next = skip;
-                            }
-                            if (!stay) {
-                                if (next == self.x) next = self.y;        // never enter the hit object's own tree (:331)
-                                if (next < n) { na = nodes4[2 * (size_t)next]; nb = nodes4[2 * (size_t)next + 1]; }
-                                i = next;
-                            }
-                        }
-                        uint32_t pre = 0, tot = 0;
-                        #pragma unroll
-                        for (int bit = 0; bit < 4; bit++) {
-                            const unsigned long long m = __ballot((cnt >> bit) & 1u);
-                            pre += lane_prefix(m) << bit;
-                            tot += (uint32_t)__popcll(m) << bit;
-                        }
-                        for (uint32_t k = 0; k < cnt; k++) q[qn + pre + k] = ((first + k) << 6) | lane;
-                        qn += tot;
-                    } else if (qn == 0) {
-                        break;
+                for (uint32_t obj0 = 0; obj0 < n_obj; obj0 += OBJ_G) {
+                    const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
+                    for (uint32_t kb = 0; kb < NQ_P * g; kb += 64) {
+                        const uint32_t k = kb + lane;
+                        const uint32_t rs = k & (NQ_P - 1), ob = k >> 4;
+                        bool ok = k < NQ_P * g && ((validm >> rs) & 1u);
+                        int32_t root = 0;
+                        if (ok) { root = s.obj_range[obj0 + ob].x; ok = root != selfr[rs].x; }   // never the hit object's own tree (:331)
+                        const unsigned long long m = __ballot(ok);
+                        if (ok) nq[nqn + lane_prefix(m)] = ((uint32_t)root << 6) | rs;
+                        nqn += (uint32_t)__popcll(m);
                     }
                     __builtin_amdgcn_wave_barrier();
-                    while (qn >= 64 || (!act && qn)) {
-                        const uint32_t m = qn < 64 ? qn : 64;
-                        qn -= m;
+                    while (nqn) {
+                        const uint32_t m = nqn < 64 ? nqn : 64;
+                        nqn -= m;
+                        uint32_t rs = 0, cnt = 0, first = 0;
+                        int32_t node = 0, info = -1, skip = 0;
+                        bool inner = false;
+                        V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
                         if (lane < m) {
-                            const uint32_t e = q[qn + lane];
-                            const uint32_t src = e & 63u, tri = e >> 6;
-                            if (!flag[src]) {
-                                const float4 ro = ray[src], rd = ray[64 + src];
-                                const size_t ti = (size_t)tri * 3;
-                                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-                                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-                                const float t = ray_triangle(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), mk(t0.x, t0.y, t0.z),
-                                                             mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
-                                if (t != SRT_NEG_INF) flag[src] = 1u;     // any t >= 0, NaN included (:335)
+                            const uint32_t e = nq[nqn + lane];
+                            rs = e & 63u; node = (int32_t)(e >> 6);
+                            if (!flag[rs]) {                          // already shadowed rays drop their queued pairs
+                                const float4 a = nodes4[2 * (size_t)node], b = nodes4[2 * (size_t)node + 1];
+                                const float4 o4 = ray[rs], d4 = ray[NQ_P + rs];
+                                ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
+                                skip = __float_as_int(b.z); info = __float_as_int(b.w);
+                                if (ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                    if (info < 0) inner = true;
+                                    else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long im = __ballot(inner);
+                        const uint32_t n_in = (uint32_t)__popcll(im);
+                        if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
+                            if (inner) {
+                                const uint32_t pos = nqn + 2 * lane_prefix(im);
+                                nq[pos] = ((uint32_t)(~info) << 6) | rs;
+                                nq[pos + 1] = ((uint32_t)(node + 1) << 6) | rs;
+                            }
+                            nqn += 2 * n_in;
+                            push_tris(first, cnt, rs);
+                        } else {
+                            push_tris(first, cnt, rs);
+                            int32_t i = inner ? node + 1 : 0, end = inner ? skip : 0;
+                            while (__ballot(i < end)) {
+                                uint32_t c2 = 0, f2 = 0;
+                                if (i < end) {
+                                    if (flag[rs]) { i = end; }
+                                    else {
+                                        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+                                        const int32_t sk = __float_as_int(b.z), inf2 = __float_as_int(b.w);
+                                        if (ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                            if (inf2 >= 0) { c2 = (uint32_t)(inf2 & LEAF_MAX); f2 = (uint32_t)(inf2 >> LEAF_SHIFT); }
+                                            i = i + 1;
+                                        } else {
+                                            i = sk;
+                                        }
+                                    }
+                                }
+                                push_tris(f2, c2, rs);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+                while (tqn) tri_batch();
                 __builtin_amdgcn_wave_barrier();
-                shadowed = flag[lane] != 0u;
+                shadowed = valid && flag[lane] != 0u;
                 __builtin_amdgcn_wave_barrier();
             }
-            if (shadowed && valid) atomicOr(&bits[lg], 1ull << pl);
+            if (shadowed && valid) atomicOr(&bits[lg], 1ull << ((qy * 4 + (pl >> 2)) * 8 + qx * 4 + (pl & 3)));
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < Lg) shadow_bits[tile_index * p.n_lights + l0 + lane] = bits[lane];
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (threadIdx.x < Lg) shadow_bits[tile_index * p.n_lights + l0 + threadIdx.x] = bits[threadIdx.x];
+        __syncthreads();
     }
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
 }
@@ -532,7 +768,7 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
     const size_t pix = (size_t)r * p.W + px;
     const int32_t id = hit_id[pix];
     if (id < 0) return;
-    const size_t tile_index = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+    const size_t tile_index = (size_t)(blockIdx.y * 2 + (wave >> 1)) * ((p.W + 7) / 8) + blockIdx.x * 2 + (wave & 1);   // 8x8 tile
     const float t = t_in[pix];
     const V3 o = mk(0.0f, 0.0f, 0.0f);
     const V3 d = primary_dir(p, px, image_row(p, r));
