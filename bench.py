@@ -35,8 +35,9 @@ BLOCK_ROWS = 16                 # scanline block size for the multi-GPU block-cy
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=36, help="frames rendered per step (the reference renders a 36-frame orbit per run)")
     ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -64,7 +65,7 @@ def main():
     build.build_all()
     lib.load()
 
-    W, H, L = args.width, args.height, args.lights
+    W, H, L, B = args.width, args.height, args.lights, args.frames
     g = gu.GoldenScene(args.workload)
     scene = lib.DeviceScene(g.flat, device=local_rank)
     lights = abi.light_staircase(g.light, L)
@@ -75,14 +76,18 @@ def main():
     hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
     tbuf = torch.empty((rows, W), dtype=torch.float32, device=dev)
     lin = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
-    # the 8-bit framebuffer tile lives in the gather object (padded to equal rows on every rank) so
-    # that the kernel writes straight into the buffer the collective sends
-    gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev)
-    rgb8 = gather.tile
+    # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
+    # on every rank) so that the kernels write straight into the buffer the collective sends
+    gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B)
     stream = torch.cuda.current_stream().cuda_stream
+    frame_bytes = gather.tile[0].numel()
 
     def step():
-        scene.render_device(p, stream=stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(), rgb_linear=lin.data_ptr(), rgb8=rgb8.data_ptr())
+        # one step = B frames (the reference's main() renders a 36-frame orbit per run, simple_raytracer.cpp:534):
+        # every rank renders its scanline blocks of each frame, then ONE gather moves all B tiles to rank 0
+        for f in range(B):
+            scene.render_device(p, stream=stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(), rgb_linear=lin.data_ptr(),
+                                rgb8=gather.tile.data_ptr() + f * frame_bytes)
         if world > 1:
             gather.gather()
 
@@ -105,6 +110,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    rgb8 = gather.tile[0]
 
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
@@ -120,7 +126,7 @@ def main():
     else:
         rays_total, prim_total, shad_total = float(rays_rank), float(sc["primary_rays"]), float(sc["shadow_rays"])
     ms_step = dt / args.steps * 1e3
-    value = rays_total / (dt / args.steps) / 1e6
+    value = rays_total * B / (dt / args.steps) / 1e6
 
     if rank == 0:
         pixels = W * rows
@@ -129,10 +135,10 @@ def main():
         # algorithmic bytes per launch: 32 B per slab test + 36 B per Moller-Trumbore test of the kernel's own
         # traversal + the per-pixel / per-item records each kernel must read and write
         kern = {
-            "k_closest_hit_q": dict(ms=st["ms_primary"],
+            "k_closest_hit_nq": dict(ms=st["ms_primary"],
                                     bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"]
                                     + 8 * pixels + 15 * miss),
-            "k_shadow": dict(ms=st["ms_shadow"],
+            "k_shadow_nq": dict(ms=st["ms_shadow"],
                              bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8),
             "k_shade_tile": dict(ms=st["ms_shade"], bytes=4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8),
         }
@@ -149,10 +155,11 @@ def main():
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
                        else f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]",
                        "scene": f"tests/golden/scene_{args.workload}.npz", "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
-                       "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + RCCL gather",
-                       "primary_rays": prim_total, "shadow_rays": shad_total},
+                       "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step",
+                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5),
+                       "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L),
                          "algorithmic_bytes_per_launch": kern[dom]["bytes"], "kernel_ms": round(kern[dom]["ms"], 5),
                          "note": "algorithmic bytes = 32 B x slab tests + 36 B x triangle tests (+ per-pixel output bytes) of the "
                                  "kernel's own traversal; the scene (3.3 MB) is L2/Infinity-Cache resident, so this is an effective rate"},
@@ -160,10 +167,44 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, W, H, L, lights)
+            if L == 1:
+                out["cpu_reference"] = cpu_reference(g, W, H)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(workload, kernel, W, H, L):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written
+    by profiles/pmc_summary.py from FETCH_SIZE / WRITE_SIZE collected in separate passes), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return t.get(f"{workload}_{W}x{H}_L{L}", {}).get(kernel)
+
+
+def cpu_reference(g, W, H):
+    """The reference's OWN hot path (oracle/_ref, compiled from its sources in the build container), one
+    thread as the reference is, one frame of the same workload.  Extra context beside cpu_baseline."""
+    from oracle import pyoracle as po
+    if not po.ref_available() or g.recipe is None:
+        return None
+    import golden_util as gu
+    try:
+        s = po.RefScene()
+        g.recipe.replay(s, {k: gu.load_mesh(k) for k in g.recipe.meshes})
+        flat = s.export()
+        t0 = time.perf_counter()
+        img, n = s.render(W, H, list(g.light) + [1.0])
+        el = time.perf_counter() - t0
+        hits = int((img.sum(-1) > 0).sum())
+        return {"value": round((W * H + hits) / el / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": f"1 frame {W}x{H} through the compiled reference's sendRaysAndIntersectPointsColors in {el:.2f} s"}
+    except Exception as e:      # the prebuilt checker is optional on the GPU box
+        return {"error": str(e)}
 
 
 def cpu_baseline(g, W, H, L, lights):

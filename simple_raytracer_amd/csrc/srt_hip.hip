@@ -30,7 +30,6 @@ static thread_local int g_last_hip = 0;
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return SRT_ERR_DEVICE; } \
     } while (0)
 
-constexpr int NCTR = 8 + 8 * 64;  // device work counters: [1..4] node/tri tests, [8 + 8*shard] sharded hit counts
 constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
 
 struct srt_scene {
@@ -42,7 +41,9 @@ struct srt_scene {
     int32_t* ws_hit = nullptr; float* ws_t = nullptr; size_t ws_pixels = 0;
     float* ws_lin = nullptr; uint8_t* ws_rgb8 = nullptr; size_t ws_out_pixels = 0;
     float* d_lights = nullptr; float* h_lights = nullptr; uint32_t lights_cap = 0, lights_valid = 0;
-    unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;
+    unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;   // device: two sets used alternately
+    unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
+    uint64_t render_seq = 0;
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
     int n_cu = 256;
     hipEvent_t ev[RING][4] = {};     // start, closest-hit done, shadow done, shade done
@@ -265,7 +266,8 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     }
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
-    hipError_t e = hipMalloc((void**)&s->d_counters, NCTR * sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
     for (int i = 0; i < RING * 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i / 4][i % 4]);
     hipDeviceProp_t prop;
@@ -330,7 +332,12 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         HIP_TRY(hipMemcpyAsync(s->d_lights, s->h_lights, light_bytes, hipMemcpyHostToDevice, stream));
         s->lights_valid = p->n_lights;
     }
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, NCTR * sizeof(unsigned long long), stream));
+    // Work / hit counters: two sets used alternately.  The last kernel of a render zeroes the set the NEXT
+    // render will use, so no memset or copy is enqueued per frame; srt_sync reads the last set.
+    unsigned long long* ctr = s->d_counters + (s->render_seq & 1) * NCTR;
+    unsigned long long* ctr_next = s->d_counters + ((s->render_seq + 1) & 1) * NCTR;
+    s->render_seq++;
+    s->d_ctr_last = ctr;
 
     DevParams dp;
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
@@ -355,22 +362,22 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     hipEvent_t* ev = s->ev[s->ring_count % RING];
     HIP_TRY(hipEventRecord(ev[0], stream));
     if (variant == 1) {                // v0 reference kernels: per-lane walk with inline triangle loop, per-pixel shade
-        if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
-        else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->d_counters);
+        if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, ctr);
+        else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, ctr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], stream));
         HIP_TRY(hipEventRecord(ev[2], stream));
-        if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
-        else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+        if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr, ctr_next);
+        else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr, ctr_next);
         HIP_TRY(hipGetLastError());
     } else {
         const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);      // node-queue kernel: 4x4 pixels per wave, 8x8 per workgroup
         #define LAUNCH_NQ(CAP) do { \
-            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters); \
-            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters); } while (0)
+            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); \
+            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); } while (0)
         if (variant == 2) {            // one ray per lane + triangle queue
-            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
-            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->d_counters);
+            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
+            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
         } else if (variant == 3) {     // tiny node queue: exercises the stackless overflow path
             LAUNCH_NQ(160);
         } else {
@@ -380,19 +387,18 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], stream));
         if (p->n_lights) {
-            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
-            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
-            else                   hipLaunchKernelGGL((k_shadow_nq<false, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, s->d_counters);
+            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, d_rgb_linear, d_rgb8);
+        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, d_rgb_linear, d_rgb8, ctr_next);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[3], stream));
     s->last_done = ev[3];
     s->ring_count++;
-    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     s->last_stream = stream;
     s->pending = true;
     s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
@@ -419,6 +425,7 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
         s->last.ms_total = (float)(c / n);
         s->last.launches = n;
         s->ring_count = 0;
+        HIP_TRY(hipMemcpy(s->h_counters, s->d_ctr_last, NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long hits = 0;
         for (int k = 0; k < 64; k++) hits += s->h_counters[8 + 8 * k];
         s->last.hit_rays = hits;

@@ -56,6 +56,13 @@ __device__ __forceinline__ void count_hits(unsigned long long* counters, bool is
     }
 }
 
+constexpr int NCTR = 8 + 8 * HIT_SHARDS;        // [1..4] node / triangle tests, [8 + 8*shard] hit counts
+// The last kernel of a render clears the counter set of the next render (two sets alternate).
+__device__ __forceinline__ void zero_next_counters(unsigned long long* next) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < NCTR; i += 256) next[i] = 0ull;
+}
+
 // 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
 // a wave are neighbours, so they walk the same top-of-tree nodes (loads of one node by many lanes
 // coalesce into one 32 B fetch) and diverge only deep in the tree.
@@ -489,7 +496,9 @@ __device__ __forceinline__ bool any_hit(const DevScene& s, int32_t self_obj, V3 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                const float* __restrict__ t_in, float* __restrict__ rgb_linear,
-                                               uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+                                               uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
+                                               unsigned long long* __restrict__ counters_next) {
+    zero_next_counters(counters_next);
     uint32_t px, r;
     const bool live = tile_pixel(p, px, r);
     unsigned long long n_node = 0, n_tri = 0;
@@ -761,7 +770,9 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
 __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                     const float* __restrict__ t_in,
                                                     const unsigned long long* __restrict__ shadow_bits,
-                                                    float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8) {
+                                                    float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                    unsigned long long* __restrict__ counters_next) {
+    zero_next_counters(counters_next);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t px, r;
     if (!tile_pixel(p, px, r)) return;

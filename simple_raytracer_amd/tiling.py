@@ -22,30 +22,34 @@ class FrameGather:
     Every rank's tile is padded to the same number of rows so that the exchange is ONE equal-size
     gather per frame (7 peers -> rank 0, each over its own xGMI link)."""
 
-    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0):
+    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1):
         self.W, self.H, self.block_rows, self.rank, self.world, self.dst = width, height, block_rows, rank, world, dst
         self.rows_of = [abi.rows_owned(height, block_rows, r, world) for r in range(world)]
         self.rows = len(self.rows_of[rank])
         self.max_rows = max(len(r) for r in self.rows_of)
-        self.tile = torch.zeros((self.max_rows, width, channels), dtype=dtype, device=device)
+        self.frames = frames
+        # [frames, rows, W, C]: a step's frames travel in ONE collective (few, large messages suit the
+        # point-to-point xGMI links: 7 peers -> rank 0, each over its own link)
+        self.tile = torch.zeros((frames, self.max_rows, width, channels), dtype=dtype, device=device)
         if rank == dst:
-            self.recv = [torch.empty_like(self.tile) for _ in range(world)]
-            self.frame = torch.empty((height, width, channels), dtype=dtype, device=device)
+            self.recv = [torch.empty_like(self.tile) for _ in range(world)] if world > 1 else None
+            self.frame = torch.empty((frames, height, width, channels), dtype=dtype, device=device)
             self.index = [torch.as_tensor(np.asarray(r), dtype=torch.long, device=device) for r in self.rows_of]
         else:
             self.recv, self.frame, self.index = None, None, None
 
     def gather(self):
-        """Gather every rank's `tile` to rank dst and de-interleave into `frame` (returned on dst, else None)."""
+        """Gather every rank's `tile` to rank dst and de-interleave into `frame` [frames, H, W, C] (returned on
+        dst, else None)."""
         if self.world == 1:
-            return self.tile[: self.rows]
+            return self.tile[:, : self.rows]
         dist.gather(self.tile, self.recv, dst=self.dst)
         if self.rank != self.dst:
             return None
         for r in range(self.world):
             n = len(self.rows_of[r])
             if n:
-                self.frame.index_copy_(0, self.index[r], self.recv[r][:n])
+                self.frame.index_copy_(1, self.index[r], self.recv[r][:, :n])
         return self.frame
 
 

@@ -32,15 +32,17 @@ def _worker(rank, world, port, block_rows, W, H, L, q):
         lights = abi.light_staircase(g.light, L)
         p = tiling.split_params(W, H, lights, rank, world, block_rows)
         o = po.render(g.flat, p, n_threads=1)
-        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"))
-        assert fg.rows == o["rgb8"].shape[0]
-        fg.tile[: fg.rows].copy_(torch.from_numpy(o["rgb8"]))
+        assert tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu")).rows == o["rgb8"].shape[0]
+        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), frames=2)
+        fg.tile[0, : fg.rows].copy_(torch.from_numpy(o["rgb8"]))
+        fg.tile[1, : fg.rows].copy_(torch.from_numpy(255 - o["rgb8"]))
         frame = fg.gather()
         hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32)
-        hg.tile[: hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
+        hg.tile[0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
         hits = hg.gather()
         if rank == 0:
-            q.put((frame.numpy().copy(), hits.numpy()[..., 0].copy()))
+            assert torch.equal(frame[1], 255 - frame[0])
+            q.put((frame[0].numpy().copy(), hits[0].numpy()[..., 0].copy()))
         else:
             assert frame is None
         dist.barrier()
