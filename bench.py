@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 logic on a box with fewer "
+                         "GPUs than ranks (ranks share devices, tiles are staged through host memory)")
     ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
     args = ap.parse_args()
 
@@ -58,10 +61,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     build.build_all()
     lib.load()
 
@@ -78,7 +86,8 @@ def main():
     lin = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
-    gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B)
+    gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B,
+                                stage_through_host=(args.backend == "gloo"))
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
@@ -107,7 +116,7 @@ def main():
     dt = time.perf_counter() - t0
     st = scene.sync()                 # HIP-event kernel times averaged over (up to 64 of) the timed launches
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     rgb8 = gather.tile[0]
@@ -120,7 +129,8 @@ def main():
     sc = scene.sync()
     rays_rank = sc["primary_rays"] + sc["shadow_rays"]
     if world > 1:
-        rr = torch.tensor([rays_rank, sc["primary_rays"], sc["shadow_rays"]], dtype=torch.float64, device=dev)
+        rr = torch.tensor([rays_rank, sc["primary_rays"], sc["shadow_rays"]], dtype=torch.float64,
+                          device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(rr)
         rays_total, prim_total, shad_total = [float(x) for x in rr.tolist()]
     else:
@@ -142,6 +152,9 @@ def main():
                              bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8),
             "k_shade_tile": dict(ms=st["ms_shade"], bytes=4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8),
         }
+        if args.variant == 0:      # shipped: closest hit + shadow rays in one launch
+            a, b = kern.pop("k_closest_hit_nq"), kern.pop("k_shadow_nq")
+            kern = {"k_trace_nq": dict(ms=st["ms_primary"] + st["ms_shadow"], bytes=a["bytes"] + b["bytes"]), **kern}
         if args.variant == 1:
             kern = {"k_closest_hit": dict(ms=st["ms_primary"], bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"] + 8 * pixels),
                     "k_shade": dict(ms=st["ms_shade"], bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 12 * hits + 23 * pixels)}
@@ -151,6 +164,7 @@ def main():
             "metric": "Mrays/sec (primary+shadow) at 1920x1080", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
                        else f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]",
@@ -159,7 +173,7 @@ def main():
                        "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5),
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,
                          "algorithmic_bytes_per_launch": kern[dom]["bytes"], "kernel_ms": round(kern[dom]["ms"], 5),
                          "note": "algorithmic bytes = 32 B x slab tests + 36 B x triangle tests (+ per-pixel output bytes) of the "
                                  "kernel's own traversal; the scene (3.3 MB) is L2/Infinity-Cache resident, so this is an effective rate"},

@@ -162,6 +162,20 @@ int srt_sync(srt_scene* s, srt_stats* stats);
  * the bytes model: 32 B per node test, 36 B per triangle test. */
 uint64_t srt_scene_device_bytes(const srt_scene* s);
 
+/* ---- known-answer entry points: the DEVICE leaf functions on caller vectors (host pointers), so that the
+ * reference's known-answer fixtures pin the device code directly.  Layouts as in tests/golden/kat.npz:
+ * ray_od = n x (origin xyz, direction xyz); box = n x (min xyz, max xyz); tri_points = n x 3 x xyzw.
+ *   srt_kat_ray_aabb      intersectRayAabbNoOrigin (simple_raytracer.cpp:252-293): the literal form, the
+ *                         branch-free form and the filtered form (+ its "ambiguous, use the exact form" flag)
+ *   srt_kat_ray_triangle  rayTriangleIntersection (:42-75): t, -inf = miss
+ *   srt_kat_phong         phongIllumination (:144-200): in28 = ray_od(6) tri(12) light(3) colour(3) ka ks shin t
+ *   srt_kat_tonemap       Reinhard + gamma (:391-398) and the quantiser (:447-449)                         */
+int srt_kat_ray_aabb(int device, uint32_t n, const float* ray_od, const float* box, uint8_t* exact, uint8_t* branchless,
+                     uint8_t* filtered, uint8_t* ambiguous);
+int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const float* tri_points, float* t);
+int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb);
+int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q);
+
 const char* srt_strerror(int code);
 int         srt_last_hip_error(void);
 uint32_t    srt_abi_version(void);

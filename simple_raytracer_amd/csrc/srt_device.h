@@ -89,6 +89,53 @@ __device__ __forceinline__ bool ray_aabb_nb(V3 o, V3 d, float mnx, float mny, fl
     return !(rej_xy | rej_z);
 }
 
+// Filtered form of the same predicate.  The six quotients are approximated as (box - o) * rcp(d) -- the
+// subtraction is the reference's own, so only the division is approximate (<= ~3 ulp against the
+// reference's correctly rounded quotient).  Every comparison of the reference is then decided with a
+// margin that covers the error of both operands (min / max selection is 1-Lipschitz, so the folded
+// interval ends keep a relative error of a few ulp of their own magnitude); if any comparison falls
+// inside its margin, or anything is not finite, `ambiguous` is set and the caller must evaluate
+// ray_aabb_nb instead.  When `ambiguous` is false the returned bool equals the reference's.
+struct RayRcp { float x, y, z; };
+__device__ __forceinline__ RayRcp ray_rcp(V3 d) {
+    RayRcp r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y); r.z = __builtin_amdgcn_rcpf(d.z); return r;
+}
+__device__ __forceinline__ bool ray_aabb_filtered(V3 o, RayRcp rc, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                                  bool& ambiguous) {
+    const float E = 2.0e-6f, TINY = 1.0e-37f;
+    const float x0 = (mnx - o.x) * rc.x, x1 = (mxx - o.x) * rc.x;
+    const float y0 = (mny - o.y) * rc.y, y1 = (mxy - o.y) * rc.y;
+    const float z0 = (mnz - o.z) * rc.z, z1 = (mxz - o.z) * rc.z;
+    float minX = __builtin_fminf(x0, x1), maxX = __builtin_fmaxf(x0, x1);
+    const float minY = __builtin_fminf(y0, y1), maxY = __builtin_fmaxf(y0, y1);
+    const float minZ = __builtin_fminf(z0, z1), maxZ = __builtin_fmaxf(z0, z1);
+    // magnitude of everything involved: non-finite anywhere -> ambiguous (0 * inf, x / 0, overflow)
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0) + __builtin_fabsf(x1), __builtin_fabsf(y0) + __builtin_fabsf(y1)),
+                                      __builtin_fabsf(z0) + __builtin_fabsf(z1));
+    bool amb = !(big < 1.0e30f) | !(x0 == x0) | !(x1 == x1) | !(y0 == y0) | !(y1 == y1) | !(z0 == z0) | !(z1 == z1);
+    // decide (a < b): certain when |a - b| exceeds the margin
+    #define SRT_LT(a, b, res)                                                            \
+        {                                                                                \
+            const float m_ = E * (__builtin_fabsf(a) + __builtin_fabsf(b)) + TINY;      \
+            const float df_ = (b) - (a);                                                 \
+            res = df_ > 0.0f;                                                            \
+            amb |= !(__builtin_fabsf(df_) > m_);                                         \
+        }
+    bool r1, r2, r3, r4;
+    SRT_LT(maxX, minY, r1);            // maxXT < minYT
+    SRT_LT(maxY, minX, r2);            // maxYT < minXT
+    const bool rej_xy = r1 | r2;
+    minX = __builtin_fmaxf(minX, minY);    // if (minYT > minXT) minXT = minYT
+    maxX = __builtin_fminf(maxX, maxY);    // if (maxYT < maxXT) maxXT = maxYT
+    SRT_LT(maxZ, minX, r3);            // minXT > maxZT
+    SRT_LT(maxX, minZ, r4);            // minZT > maxXT
+    #undef SRT_LT
+    // the z comparisons only matter when the xy test did not reject; their ambiguity is ignored otherwise
+    // (conservative: an ambiguous z comparison of an xy-rejected box still falls back, which is only slower)
+    ambiguous = amb;
+    return !(rej_xy | r3 | r4);
+}
+
 // ---- a5: rayTriangleIntersection, simple_raytracer.cpp:42-75 (Moller-Trumbore) ------------------
 // Returns -inf on a miss, t >= 0 on a hit, NaN when NaN falls through every test (as the reference).
 __device__ __forceinline__ float ray_triangle(V3 o, V3 d, V3 p1, V3 e1, V3 e2) {

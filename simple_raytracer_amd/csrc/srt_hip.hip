@@ -371,25 +371,44 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr, ctr_next);
         HIP_TRY(hipGetLastError());
     } else {
-        const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);      // node-queue kernel: 4x4 pixels per wave, 8x8 per workgroup
-        #define LAUNCH_NQ(CAP) do { \
-            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); \
-            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); } while (0)
-        if (variant == 2) {            // one ray per lane + triangle queue
+        const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);      // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
+        // closest-hit kernel: CAP = node queue entries, TWL/THL = log2 tile size per wave, FILTER = filtered slab test
+        #define LAUNCH_NQ(CAP, TWL, THL, FILTER) do { \
+            const dim3 g_((p->width + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
+            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); \
+            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); } while (0)
+        switch (variant) {
+        case 2:                        // one ray per lane + triangle queue
             if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
             else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
-        } else if (variant == 3) {     // tiny node queue: exercises the stackless overflow path
-            LAUNCH_NQ(160);
-        } else {
-            LAUNCH_NQ(1024);
+            break;
+        case 3: LAUNCH_NQ(160, 2, 2, false); break;      // tiny node queue: exercises the stackless overflow path
+        case 4: LAUNCH_NQ(512, 2, 2, false); break;      // shipped geometry with exact divides only
+        case 5: LAUNCH_NQ(1024, 3, 2, false); break;     // 8x4 pixels per wave
+        case 6: LAUNCH_NQ(1024, 2, 1, false); break;     // 4x2
+        case 7: LAUNCH_NQ(1024, 2, 2, false); break;     // larger node queue
+        case 8: LAUNCH_NQ(2048, 3, 3, false); break;     // 8x8
+        case 9: LAUNCH_NQ(512, 2, 1, true); break;
+        case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
+        default:                                           // shipped: closest hit + shadow rays fused in one launch
+            if (p->n_lights) {
+                if (count) hipLaunchKernelGGL((k_trace_nq<true, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->ws_shadow, ctr);
+                else       hipLaunchKernelGGL((k_trace_nq<false, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->ws_shadow, ctr);
+            } else {
+                LAUNCH_NQ(512, 2, 2, true);
+            }
+            break;
         }
         #undef LAUNCH_NQ
+        const bool fused = (variant == 0 || variant > 10) && p->n_lights;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev[1], stream));
-        if (p->n_lights) {
-            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else                   hipLaunchKernelGGL((k_shadow_nq<false, 1024>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+        if (p->n_lights && !fused) {
+            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else if (variant == 7) hipLaunchKernelGGL((k_shadow_nq<false, 1024, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev[2], stream));
@@ -467,6 +486,67 @@ int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, flo
         if (rgb8) HIP_TRY(hipMemcpy(rgb8, s->ws_rgb8, pixels * 3, hipMemcpyDeviceToHost));
     }
     return SRT_OK;
+}
+
+// ---- known-answer entry points (device leaf functions on caller vectors; host pointers in and out) ----
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { hipError_t e = hipMalloc(&p, bytes ? bytes : 1); if (e != hipSuccess) { g_last_hip = (int)e; return SRT_ERR_DEVICE; } return SRT_OK; }
+    int up(const void* h, size_t bytes) { int rc = alloc(bytes); if (rc) return rc; HIP_TRY(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice)); return SRT_OK; }
+    int down(void* h, size_t bytes) { HIP_TRY(hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost)); return SRT_OK; }
+};
+}
+#define KAT_TRY(expr) do { int rc_ = (expr); if (rc_ != SRT_OK) return rc_; } while (0)
+
+int srt_kat_ray_aabb(int device, uint32_t n, const float* ray_od, const float* box, uint8_t* exact, uint8_t* branchless,
+                     uint8_t* filtered, uint8_t* ambiguous) {
+    if (!n || !ray_od || !box || !exact || !branchless || !filtered || !ambiguous) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf r, b, o0, o1, o2, o3;
+    KAT_TRY(r.up(ray_od, (size_t)n * 24)); KAT_TRY(b.up(box, (size_t)n * 24));
+    KAT_TRY(o0.alloc(n)); KAT_TRY(o1.alloc(n)); KAT_TRY(o2.alloc(n)); KAT_TRY(o3.alloc(n));
+    hipLaunchKernelGGL(k_kat_ray_aabb, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)r.p, (const float*)b.p,
+                       (uint8_t*)o0.p, (uint8_t*)o1.p, (uint8_t*)o2.p, (uint8_t*)o3.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    KAT_TRY(o0.down(exact, n)); KAT_TRY(o1.down(branchless, n)); KAT_TRY(o2.down(filtered, n)); KAT_TRY(o3.down(ambiguous, n));
+    return SRT_OK;
+}
+
+int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const float* tri_points, float* t) {
+    if (!n || !ray_od || !tri_points || !t) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<DevTri> tris(n);
+    for (uint32_t i = 0; i < n; i++) tris[i] = derive_triangle(tri_points + 12 * (size_t)i);
+    DevBuf r, q, o;
+    KAT_TRY(r.up(ray_od, (size_t)n * 24)); KAT_TRY(q.up(tris.data(), (size_t)n * sizeof(DevTri))); KAT_TRY(o.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(k_kat_ray_triangle, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)r.p, (const DevTri*)q.p, (float*)o.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    return o.down(t, (size_t)n * 4);
+}
+
+int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb) {
+    if (!n || !in28 || !rgb) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<DevTri> tris(n);
+    for (uint32_t i = 0; i < n; i++) tris[i] = derive_triangle(in28 + 28 * (size_t)i + 6);
+    DevBuf a, q, o;
+    KAT_TRY(a.up(in28, (size_t)n * 28 * 4)); KAT_TRY(q.up(tris.data(), (size_t)n * sizeof(DevTri))); KAT_TRY(o.alloc((size_t)n * 12));
+    hipLaunchKernelGGL(k_kat_phong, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, (const DevTri*)q.p, (float*)o.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    return o.down(rgb, (size_t)n * 12);
+}
+
+int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q) {
+    if (!n || !lin || !tone || !q) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf a, o, o2;
+    KAT_TRY(a.up(lin, (size_t)n * 12)); KAT_TRY(o.alloc((size_t)n * 12)); KAT_TRY(o2.alloc((size_t)n * 12));
+    hipLaunchKernelGGL(k_kat_tonemap, dim3((3 * n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, reinhard, gamma, (float*)o.p, (int32_t*)o2.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    KAT_TRY(o.down(tone, (size_t)n * 12));
+    return o2.down(q, (size_t)n * 12);
 }
 
 } // extern "C"

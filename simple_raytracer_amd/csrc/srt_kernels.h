@@ -277,34 +277,32 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
 // If the node queue cannot take a step's children the wave finishes those subtrees with the stackless
 // pre-order walk (skip links) instead -- any tree shape is handled with bounded LDS.
 // =================================================================================================
-constexpr int NQ_P = 16;                    // pixels per wavefront (4x4)
+constexpr int NQ_P = 16;                    // rays per wavefront of the shadow kernel (4x4 pixel quadrant)
 
-template <bool COUNT, int NQCAP>
-__global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
-                                                        float* __restrict__ t_out, float* __restrict__ rgb_linear,
-                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][QCAP];
-    __shared__ unsigned long long best_all[4][NQ_P];
-    __shared__ float2 dir_all[4][NQ_P];
+// TWL / THL: log2 of the tile width / height a wavefront owns (shipped: 4x4); FILTER: filtered slab predicate.
+// The phase runs per wavefront on LDS the caller provides: nq[NQCAP], tq[QCAP], best[P], dir[P].  On return the
+// lanes < P hold their pixel's hit id and t (also written to hit_id / t_out, with the final pixel for misses).
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
+__device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq,
+                                                  unsigned long long* best, float2* dir,
+                                                  int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                  float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                  unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t) {
+    constexpr int P = 1 << (TWL + THL);           // rays per wavefront
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* nq = nq_all[wave];
-    uint32_t* tq = tq_all[wave];
-    unsigned long long* best = best_all[wave];
-    float2* dir = dir_all[wave];
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
-    const uint32_t tile_x = blockIdx.x * 8 + (wave & 1) * 4, tile_r = blockIdx.y * 8 + (wave >> 1) * 4;
-    const uint32_t px = tile_x + (lane & 3), r = tile_r + ((lane >> 2) & 3);
-    const bool live = lane < NQ_P && px < p.W && r < p.rows;
+    const uint32_t tile_x = (blockIdx.x * 2 + (wave & 1)) << TWL, tile_r = (blockIdx.y * 2 + (wave >> 1)) << THL;
+    const uint32_t px = tile_x + (lane & ((1u << TWL) - 1)), r = tile_r + ((lane >> TWL) & ((1u << THL) - 1));
+    const bool live = lane < P && px < p.W && r < p.rows;
     const V3 o = mk(0.0f, 0.0f, 0.0f);
     V3 dmine = mk(0.f, 0.f, p.focal);
-    if (lane < NQ_P) {
+    if (lane < P) {
         best[lane] = ~0ull;
         if (live) dmine = primary_dir(p, px, image_row(p, r));
         dir[lane] = make_float2(dmine.x, dmine.y);
     }
-    const uint32_t livem = (uint32_t)__ballot(live);
+    const unsigned long long livem = __ballot(live);
     unsigned long long n_node = 0, n_tri = 0;
     uint32_t nqn = 0, tqn = 0;                       // wave-uniform queue lengths
     __builtin_amdgcn_wave_barrier();
@@ -351,15 +349,15 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     };
 
     const uint32_t n_obj = s.n_objects;
-    const uint32_t nlive = (uint32_t)__popc(livem);
-    constexpr uint32_t OBJ_G = (NQCAP / 32) < 16 ? (NQCAP / 32) : 16;      // roots pushed at once: 16 * OBJ_G <= NQCAP / 2
+    const uint32_t nlive = (uint32_t)__popcll(livem);
+    constexpr uint32_t OBJ_G = (NQCAP / (2 * P)) < 16 ? (NQCAP / (2 * P)) : 16;      // roots pushed at once: P * OBJ_G <= NQCAP / 2
     for (uint32_t obj0 = 0; obj0 < n_obj && nlive; obj0 += OBJ_G) {
         // roots of up to OBJ_G objects for every live pixel, in chunks of 64 (node, pixel) pairs
         const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
-        for (uint32_t base = 0; base < NQ_P * g; base += 64) {
+        for (uint32_t base = 0; base < P * g; base += 64) {
             const uint32_t k = base + lane;
-            const uint32_t pl = k & (NQ_P - 1), ob = k >> 4;
-            const bool ok = k < NQ_P * g && ((livem >> pl) & 1u);
+            const uint32_t pl = k & (P - 1), ob = k >> (TWL + THL);
+            const bool ok = k < P * g && ((livem >> pl) & 1ull);
             const unsigned long long m = __ballot(ok);
             if (ok) nq[nqn + lane_prefix(m)] = ((uint32_t)s.obj_range[obj0 + ob].x << 6) | pl;
             nqn += (uint32_t)__popcll(m);
@@ -381,7 +379,15 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
                 d = mk(dxy.x, dxy.y, p.focal);
                 skip = __float_as_int(b.z); info = __float_as_int(b.w);
                 if (COUNT) n_node++;
-                if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                bool pass;
+                if (FILTER) {
+                    bool amb;
+                    pass = ray_aabb_filtered(o, ray_rcp(d), a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                    if (amb) pass = ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y);      // rare: exact divides decide
+                } else {
+                    pass = ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y);
+                }
+                if (pass) {
                     if (info < 0) inner = true;
                     else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
                 }
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __builtin_amdgcn_wave_barrier();
 
     bool is_hit = false;
+    out_id = -1; out_t = __builtin_inff();
     if (live) {
         const unsigned long long key = best[lane];
         int32_t id = -1;
@@ -444,9 +451,25 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
             if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
         }
         is_hit = id >= 0;
+        out_id = id; out_t = t;
     }
     count_hits(counters, is_hit);
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
+__global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+                                                        float* __restrict__ t_out, float* __restrict__ rgb_linear,
+                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+    constexpr int P = 1 << (TWL + THL);
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ unsigned long long best_all[4][P];
+    __shared__ float2 dir_all[4][P];
+    const uint32_t wave = threadIdx.x >> 6;
+    int32_t id; float t;
+    closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t);
 }
 
 // =================================================================================================
@@ -569,24 +592,25 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
 // SEQ = true is the counting build: per-ray sequential pre-order walk with exit at the first hit, whose
 // slab / triangle test counts are the algorithmic counts the CPU oracle mirrors.
 // =================================================================================================
-template <bool SEQ, int NQCAP>
-__global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
-                                                   const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
-                                                   unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][QCAP];
-    __shared__ float4 ray_all[4][2 * NQ_P];          // per ray slot: origin, direction
-    __shared__ int2 self_all[4][NQ_P];               // per ray slot: node range of the hit object
-    __shared__ uint32_t flag_all[4][NQ_P];
-    __shared__ float4 pix_all[4][NQ_P];              // per hit rank: t, pixel lane, own object's node range
-    __shared__ unsigned long long bits[64];          // per light of the current group: shadowed pixels of the 8x8 tile
+// Per-wave LDS of the shadow phase (beside the two queues)
+struct ShadowLds {
+    float4 ray[2 * NQ_P];          // per ray slot: origin, direction
+    float4 pixd[NQ_P];             // per hit rank: t, pixel lane, own object's node range
+    int2 selfr[NQ_P];              // per ray slot: node range of the hit object
+    uint32_t flag[NQ_P];
+};
+
+// Runs per wavefront; `id` / `t_hit` are the hit id and t of this lane's pixel (lanes < 16; -1 = miss).  `bits`
+// is the workgroup's 64-entry word array; ALL four waves of the workgroup must call this (it synchronises).
+template <bool SEQ, int NQCAP, bool FILTER>
+__device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
+                                             unsigned long long* bits, int32_t id, float t_hit,
+                                             unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* nq = nq_all[wave];
-    uint32_t* tq = tq_all[wave];
-    float4* ray = ray_all[wave];
-    int2* selfr = self_all[wave];
-    uint32_t* flag = flag_all[wave];
-    float4* pixd = pix_all[wave];
+    float4* ray = L.ray;
+    int2* selfr = L.selfr;
+    uint32_t* flag = L.flag;
+    float4* pixd = L.pixd;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
     const uint32_t qx = wave & 1, qy = wave >> 1;
@@ -595,13 +619,12 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
     const bool live = lane < NQ_P && px < p.W && r < p.rows;
     const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     unsigned long long n_node = 0, n_tri = 0;
-    int32_t id = -1;
-    if (live) id = hit_id[(size_t)r * p.W + px];
+    if (!live) id = -1;
     const uint32_t hm = (uint32_t)__ballot(id >= 0);
     const uint32_t nh = (uint32_t)__popc(hm);
     if (id >= 0) {
         const int2 self = s.obj_range[s.tri_obj[id]];
-        pixd[__popc(hm & ((1u << lane) - 1u))] = make_float4(t_in[(size_t)r * p.W + px], __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
+        pixd[__popc(hm & ((1u << lane) - 1u))] = make_float4(t_hit, __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
     }
     uint32_t nqn = 0, tqn = 0;
 
@@ -706,7 +729,15 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
                                 const float4 o4 = ray[rs], d4 = ray[NQ_P + rs];
                                 ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
                                 skip = __float_as_int(b.z); info = __float_as_int(b.w);
-                                if (ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                bool pass;
+                                if (FILTER) {
+                                    bool amb;
+                                    pass = ray_aabb_filtered(ro, ray_rcp(rd), a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                                    if (amb) pass = ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y);
+                                } else {
+                                    pass = ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y);
+                                }
+                                if (pass) {
                                     if (info < 0) inner = true;
                                     else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
                                 }
@@ -759,6 +790,44 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
         __syncthreads();
     }
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
+}
+
+template <bool SEQ, int NQCAP, bool FILTER>
+__global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                                   const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
+                                                   unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ ShadowLds lds_all[4];
+    __shared__ unsigned long long bits[64];          // per light of the current group: shadowed pixels of the 8x8 tile
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
+    int32_t id = -1; float t = 0.f;
+    if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; }
+    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, shadow_bits, counters);
+}
+
+// =================================================================================================
+// Kernel 1+2a fused (shipped): the wavefront that found its 4x4 tile's closest hits goes straight on to the
+// tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
+// a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
+// =================================================================================================
+template <bool COUNT, int NQCAP, bool FILTER>
+__global__ __launch_bounds__(256) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                  float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                  unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ unsigned long long best_all[4][NQ_P];
+    __shared__ float2 dir_all[4][NQ_P];
+    __shared__ ShadowLds lds_all[4];
+    __shared__ unsigned long long bits[64];
+    const uint32_t wave = threadIdx.x >> 6;
+    int32_t id; float t;
+    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t);
+    __builtin_amdgcn_wave_barrier();
+    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, shadow_bits, counters);
 }
 
 // =================================================================================================
@@ -821,4 +890,43 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
         if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
         rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
     }
+}
+
+// =================================================================================================
+// Known-answer kernels: the device leaf functions on caller-supplied vectors (srt_kat_* in the ABI),
+// so that the reference's KAT fixtures pin the DEVICE code paths directly.
+// =================================================================================================
+__global__ void k_kat_ray_aabb(uint32_t n, const float* __restrict__ ray_od, const float* __restrict__ box,
+                               uint8_t* __restrict__ exact, uint8_t* __restrict__ branchless,
+                               uint8_t* __restrict__ filtered, uint8_t* __restrict__ ambiguous) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = ray_od + 6 * (size_t)i; const float* b = box + 6 * (size_t)i;
+    const V3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    exact[i] = ray_aabb(o, d, b[0], b[1], b[2], b[3], b[4], b[5]) ? 1 : 0;
+    branchless[i] = ray_aabb_nb(o, d, b[0], b[1], b[2], b[3], b[4], b[5]) ? 1 : 0;
+    bool amb;
+    filtered[i] = ray_aabb_filtered(o, ray_rcp(d), b[0], b[1], b[2], b[3], b[4], b[5], amb) ? 1 : 0;
+    ambiguous[i] = amb ? 1 : 0;
+}
+__global__ void k_kat_ray_triangle(uint32_t n, const float* __restrict__ ray_od, const DevTri* __restrict__ tris, float* __restrict__ t) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = ray_od + 6 * (size_t)i; const DevTri q = tris[i];
+    t[i] = ray_triangle(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), mk(q.p1x, q.p1y, q.p1z), mk(q.e1x, q.e1y, q.e1z), mk(q.e2x, q.e2y, q.e2z));
+}
+// in: ray_od(6) normal-from-DevTri(3 via tris) light(3) color(3) props(3) t(1)
+__global__ void k_kat_phong(uint32_t n, const float* __restrict__ in, const DevTri* __restrict__ tris, float* __restrict__ rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in + 28 * (size_t)i; const DevTri tr = tris[i];
+    const V3 c = phong(mk(tr.nx, tr.ny, tr.nz), mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5]), mk(q[18], q[19], q[20]),
+                       mk(q[21], q[22], q[23]), q[24], q[25], q[26], q[27]);
+    rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+}
+__global__ void k_kat_tonemap(uint32_t n, const float* __restrict__ lin, float reinhard, float gamma, float* __restrict__ tone, int32_t* __restrict__ q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const float c = tone1(lin[i], reinhard, gamma);
+    tone[i] = c; q[i] = quant1(c);
 }

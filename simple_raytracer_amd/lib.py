@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 # every symbol include/srt.h declares
 ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_scene_create", "srt_scene_destroy",
                "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
-               "srt_last_hip_error", "srt_abi_version")
+               "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -62,6 +62,10 @@ def load():
         L.srt_strerror.restype = C.c_char_p
         L.srt_last_hip_error.restype = C.c_int
         L.srt_abi_version.restype = C.c_uint32
+        L.srt_kat_ray_aabb.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _u8p, _u8p, _u8p, _u8p]
+        L.srt_kat_ray_triangle.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _f32p]
+        L.srt_kat_phong.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p]
+        L.srt_kat_tonemap.argtypes = [C.c_int, C.c_uint32, _f32p, C.c_float, C.c_float, _f32p, _i32p]
         _lib = L
     return _lib
 
@@ -125,3 +129,34 @@ class DeviceScene:
         st = abi.Stats()
         _check(self.L.srt_sync(self.h, C.byref(st)), "srt_sync")
         return st.as_dict()
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def kat_ray_aabb(ray_od, box, device=0):
+    """Device slab test on vectors: returns (literal, branch-free, filtered, ambiguous) uint8 arrays."""
+    L = load(); ray_od, box = _f(ray_od), _f(box); n = ray_od.shape[0]
+    outs = [np.empty(n, np.uint8) for _ in range(4)]
+    _check(L.srt_kat_ray_aabb(device, n, ray_od.ctypes.data_as(_f32p), box.ctypes.data_as(_f32p), *[o.ctypes.data_as(_u8p) for o in outs]), "srt_kat_ray_aabb")
+    return outs
+
+
+def kat_ray_triangle(ray_od, tri_points, device=0):
+    L = load(); ray_od, tri_points = _f(ray_od), _f(tri_points); n = ray_od.shape[0]; t = np.empty(n, np.float32)
+    _check(L.srt_kat_ray_triangle(device, n, ray_od.ctypes.data_as(_f32p), tri_points.ctypes.data_as(_f32p), t.ctypes.data_as(_f32p)), "srt_kat_ray_triangle")
+    return t
+
+
+def kat_phong(in28, device=0):
+    L = load(); in28 = _f(in28); n = in28.shape[0]; rgb = np.empty((n, 3), np.float32)
+    _check(L.srt_kat_phong(device, n, in28.ctypes.data_as(_f32p), rgb.ctypes.data_as(_f32p)), "srt_kat_phong")
+    return rgb
+
+
+def kat_tonemap(lin, reinhard=0.5, gamma=1.1, device=0):
+    L = load(); lin = _f(lin).reshape(-1, 3); n = lin.shape[0]
+    tone = np.empty((n, 3), np.float32); q = np.empty((n, 3), np.int32)
+    _check(L.srt_kat_tonemap(device, n, lin.ctypes.data_as(_f32p), reinhard, gamma, tone.ctypes.data_as(_f32p), q.ctypes.data_as(_i32p)), "srt_kat_tonemap")
+    return tone, q

@@ -22,12 +22,13 @@ class FrameGather:
     Every rank's tile is padded to the same number of rows so that the exchange is ONE equal-size
     gather per frame (7 peers -> rank 0, each over its own xGMI link)."""
 
-    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1):
+    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1, stage_through_host=False):
         self.W, self.H, self.block_rows, self.rank, self.world, self.dst = width, height, block_rows, rank, world, dst
         self.rows_of = [abi.rows_owned(height, block_rows, r, world) for r in range(world)]
         self.rows = len(self.rows_of[rank])
         self.max_rows = max(len(r) for r in self.rows_of)
         self.frames = frames
+        self.stage = stage_through_host            # gloo rehearsal on a GPU box: collectives on host copies
         # [frames, rows, W, C]: a step's frames travel in ONE collective (few, large messages suit the
         # point-to-point xGMI links: 7 peers -> rank 0, each over its own link)
         self.tile = torch.zeros((frames, self.max_rows, width, channels), dtype=dtype, device=device)
@@ -43,7 +44,15 @@ class FrameGather:
         dst, else None)."""
         if self.world == 1:
             return self.tile[:, : self.rows]
-        dist.gather(self.tile, self.recv, dst=self.dst)
+        if self.stage:
+            host = self.tile.cpu()
+            recv = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(host, recv, dst=self.dst)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.recv[r].copy_(recv[r])
+        else:
+            dist.gather(self.tile, self.recv, dst=self.dst)
         if self.rank != self.dst:
             return None
         for r in range(self.world):

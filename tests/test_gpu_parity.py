@@ -148,7 +148,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -186,9 +186,52 @@ def test_big_leaves_and_signed_zero_t(srt, oracle):
                          obj_root=[0], tri_points=pts, tri_obj=np.zeros(n, np.int32),
                          obj_color=[[0.8, 0.6, 0.2]], obj_material=[[0.2, 0.5, 15.0]])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 5, 6, 7, 8, 10):
         p = abi.make_params(96, 64, [[100.0, -200.0, 50.0]], flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
         assert o["stats"]["tri_tests_primary"] == c["stats"]["tri_tests_primary"]
     assert (c["t"] == 0).any(), "test scene should contain t == 0 hits"
+
+
+# ---- device leaf functions against the reference's known-answer vectors ---------------------------
+def test_device_kat_ray_triangle(srt):
+    k = gu.load_kat()
+    for pre in ("rt", "rt2"):
+        t = srt.kat_ray_triangle(k[pre + "_ray"], k[pre + "_tri"])
+        assert np.array_equal(bits(t), bits(k[pre + "_t"])), "device Moller-Trumbore differs from the reference (bitwise)"
+
+
+def test_device_kat_ray_aabb_all_forms(srt):
+    k = gu.load_kat()
+    exact, nb, filt, amb = srt.kat_ray_aabb(k["ab_ray"], k["ab_box"])
+    assert np.array_equal(exact, k["ab_hit"]), "device slab test differs from the reference"
+    assert np.array_equal(nb, k["ab_hit"]), "branch-free slab test differs from the reference"
+    ok = amb == 0
+    assert np.array_equal(filt[ok], k["ab_hit"][ok]), "filtered slab test wrong where it claims certainty"
+    assert ok.mean() > 0.5, "filter should decide the plain cases itself"
+    # near-degenerate stress: rays through box corners / edges scaled by +-few ulp
+    rng = np.random.default_rng(9)
+    n = 200000
+    lo = rng.uniform(-100, 100, (n, 3)).astype(np.float32); lo[:, 2] += 300
+    hi = lo + rng.uniform(0, 80, (n, 3)).astype(np.float32)
+    corner = np.where(rng.integers(0, 2, (n, 3)) == 1, hi, lo)
+    ray = np.zeros((n, 6), np.float32)
+    jig = rng.integers(-3, 4, (n, 3)).astype(np.int32)
+    ray[:, 3:] = (np.ascontiguousarray(corner).view(np.int32) + jig).view(np.float32)   # +-3 ulp around the corner direction
+    ray[: n // 2, 3:5] = np.round(ray[: n // 2, 3:5])                           # integer pixel directions
+    box = np.concatenate([lo, hi], 1)
+    exact, nb, filt, amb = srt.kat_ray_aabb(ray, box)
+    assert np.array_equal(exact, nb)
+    ok = amb == 0
+    assert np.array_equal(filt[ok], exact[ok]), f"{int((filt[ok] != exact[ok]).sum())} filtered decisions are wrong"
+    assert 0 < (~ok).sum() < n, "stress set should contain both certain and ambiguous cases"
+
+
+def test_device_kat_phong_and_tonemap(srt):
+    k = gu.load_kat()
+    rgb = srt.kat_phong(k["ph_in"])
+    assert np.abs(rgb - k["ph_rgb"]).max() < 1e-6 and (bits(rgb) != bits(k["ph_rgb"])).mean() < 0.01
+    tone, q = srt.kat_tonemap(k["tm_lin"])
+    assert np.abs(tone - k["tm_tone"]).max() < 1e-6
+    assert np.abs(q - k["tm_q"]).max() <= 1 and (q != k["tm_q"]).mean() < 1e-3
