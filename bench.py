@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=36, help="frames rendered per step (the reference renders a 36-frame orbit per run)")
-    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground"])
+    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground", "soup"])
+    ap.add_argument("--tris", type=int, default=1000000, help="triangle count of the synthetic soup workload (BASELINE.json configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
@@ -74,7 +75,10 @@ def main():
     lib.load()
 
     W, H, L, B = args.width, args.height, args.lights, args.frames
-    g = gu.GoldenScene(args.workload)
+    if args.workload == "soup":
+        g = soup_workload(args.tris)
+    else:
+        g = gu.GoldenScene(args.workload)
     scene = lib.DeviceScene(g.flat, device=local_rank)
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
@@ -167,8 +171,11 @@ def main():
             **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
-                       else f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]",
-                       "scene": f"tests/golden/scene_{args.workload}.npz", "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
+                       else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
+                             else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s) [BASELINE.json configs[4], spp 1]"),
+                       "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
+                                f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
+                       "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
                        "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step",
                        "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5),
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
@@ -187,6 +194,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class soup_workload:
+    """BASELINE.json configs[4]: synthetic N-triangle soup, generator fully specified in tests/scenes.py, hierarchy built
+    by the host-side C++ mirror of the reference's builder."""
+    def __init__(self, n_tris):
+        import scenes
+        from simple_raytracer_amd import host
+        self.recipe, meshes = scenes.soup(n_tris)
+        self.flat = host.build_flat_scene(self.recipe, meshes)
+        self.light = np.array(self.recipe.light, np.float32)
+        self.recipe = None          # no reference replay for this workload in cpu_reference()
 
 
 def measured_traffic(workload, kernel, W, H, L):
@@ -226,8 +245,14 @@ def cpu_baseline(g, W, H, L, lights):
     bounded sample: whole frames of the same 1920x1080 workload for about 10 s."""
     from oracle import pyoracle as po
     from simple_raytracer_amd import abi
-    p = abi.make_params(W, H, lights)
     cores = po.oracle_lib().oracle_num_threads()
+    # bounded sample: whole frames when a frame is cheap, else a band of scanline blocks in the middle of the frame
+    band = max(1, H // 64)
+    probe = abi.make_params(W, H, lights, block_rows=band, block_first=(H // band) // 2, block_stride=10 ** 6)
+    t0 = time.perf_counter(); o = po.render(g.flat, probe, n_threads=cores); tp = time.perf_counter() - t0
+    whole = tp * (H / band) < 1.0
+    p = abi.make_params(W, H, lights) if whole else probe
+    what = f"whole frames of the same {W}x{H} workload" if whole else f"passes over the middle {band} scanlines of the same {W}x{H} workload"
     o = po.render(g.flat, p, n_threads=cores)       # warm
     rays = o["stats"]["primary_rays"] + o["stats"]["shadow_rays"]
     n, t0 = 0, time.perf_counter()
@@ -237,11 +262,12 @@ def cpu_baseline(g, W, H, L, lights):
         if el > 8.0 or n >= 200:
             break
     t1 = time.perf_counter()
-    po.render(g.flat, p, n_threads=1)
+    o1 = po.render(g.flat, probe, n_threads=1)
     el1 = time.perf_counter() - t1
+    rays1 = o1["stats"]["primary_rays"] + o1["stats"]["shadow_rays"]
     return {"value": round(rays * n / el / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} whole frames of the same {W}x{H} workload in {el:.1f} s (OpenMP over rows)",
-            "value_1_thread": round(rays / el1 / 1e6, 3)}
+            "sample": f"{n} {what} in {el:.1f} s (OpenMP over rows)",
+            "value_1_thread": round(rays1 / el1 / 1e6, 3)}
 
 
 if __name__ == "__main__":

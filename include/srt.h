@@ -98,7 +98,10 @@ typedef struct srt_params {
     float    reinhard;             /* 0.5 (:391)                                                    */
     float    gamma;                /* 1.1 (:396)                                                    */
     uint8_t  background[4];        /* 173,216,230 (:476); [3] unused                                */
-    uint32_t spp;                  /* 1 = reference; >1 = extension, sqrt(spp) x sqrt(spp) grid      */
+    uint32_t spp;                  /* 1 = reference.  n*n > 1 = EXTENSION (the reference has no supersampling):
+                                    * regular n x n sub-pixel grid, offsets (k+0.5)/n - 0.5 added to dir.xy, the
+                                    * sub-frames' pre-tone-map sums added in order, divided by spp, tone-mapped
+                                    * once; hit_id / t report sub-sample 0                            */
     uint32_t flags;
 } srt_params;
 

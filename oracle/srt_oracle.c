@@ -234,7 +234,8 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                   srt_stats* stats, int n_threads) {
     if (!d || !p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
-    if (p->spp != 1) return SRT_ERR_ARG;
+    const uint32_t spp = p->spp, spp_n = (uint32_t)lroundf(sqrtf((float)p->spp));
+    if (spp < 1 || spp_n * spp_n != spp) return SRT_ERR_ARG;      /* supersampling extension: n x n sub-pixel grid */
     scene_view s; s.d = d;
     s.geom = (tri_geom*)malloc(sizeof(tri_geom) * (d->n_tris ? d->n_tris : 1));
     s.normal = (v3*)malloc(sizeof(v3) * (d->n_tris ? d->n_tris : 1));
@@ -264,14 +265,22 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
         for (uint32_t x = 0; x < W; x++) {
             const size_t pix = (size_t)r * W + x;
             v3 o = v3make(0.0f, 0.0f, 0.0f);
-            v3 dir = v3make((float)(i0 + (int)x) + 0.0f, (float)(j0 + (int)y) + 0.0f, p->focal);
+            v3 sum = v3make(0.f, 0.f, 0.f), tone = v3make(0.f, 0.f, 0.f);
+            int32_t q[3] = { 0, 0, 0 };
+            for (uint32_t ss = 0; ss < spp; ss++) {
+            /* spp = 1: offset 0, the reference's ray (i + rayXY.x with rayXY = 0, :507,514-515); spp > 1 (extension,
+             * SURVEY.md R4): regular n x n sub-pixel grid, offsets (k + 0.5)/n - 0.5 */
+            const float sub_x = spp == 1 ? 0.0f : ((float)(ss % spp_n) + 0.5f) / (float)spp_n - 0.5f;
+            const float sub_y = spp == 1 ? 0.0f : ((float)(ss / spp_n) + 0.5f) / (float)spp_n - 0.5f;
+            v3 dir = v3make((float)(i0 + (int)x) + sub_x, (float)(j0 + (int)y) + sub_y, p->focal);
             float best = INFINITY; int32_t best_id = -1;
             for (uint32_t k = 0; k < d->n_objects; k++)                      /* rayIntersection:409 */
                 closest_in_tree(&s, (int32_t)d->obj_root[k], o, dir, &best, &best_id, &w);
-            if (hit_id) hit_id[pix] = best_id;
-            if (t_out) t_out[pix] = best;
-            v3 sum = v3make(0.f, 0.f, 0.f), tone = v3make(0.f, 0.f, 0.f);
-            int32_t q[3] = { 0, 0, 0 };
+            if (ss == 0) {
+                if (hit_id) hit_id[pix] = best_id;
+                if (t_out) t_out[pix] = best;
+            }
+            v3 ssum = v3make(0.f, 0.f, 0.f);
             if (best_id >= 0) {
                 hits++;
                 const int32_t obj = d->tri_obj[best_id];
@@ -283,7 +292,11 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                     const float* tc = d->tri_texcoord + 6 * (size_t)best_id;
                     float tx = (bc.x * tc[0] + bc.y * tc[2]) + bc.z * tc[4];   /* getTextureCoordinate:123-125 */
                     float ty = (bc.x * tc[1] + bc.y * tc[3]) + bc.z * tc[5];
-                    size_t texIndex = ((size_t)((int)ty * (int)d->tex_w[tex] + (int)tx)) * 3;   /* :357 */
+                    long long texIndex = ((long long)((int)ty * (int)d->tex_w[tex] + (int)tx)) * 3;   /* :357 */
+                    /* outside the image the reference reads out of bounds (UB); clamped like the HIP path */
+                    const long long last = (long long)d->tex_w[tex] * d->tex_h[tex] * 3 - 3;
+                    if (texIndex < 0) texIndex = 0;
+                    if (texIndex > last) texIndex = last;
                     const uint8_t* td = d->tex_rgb + d->tex_off[tex];
                     color = v3make(td[texIndex] / 255.0f, td[texIndex + 1] / 255.0f, td[texIndex + 2] / 255.0f);
                 }
@@ -293,11 +306,14 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                     int sh_hit = in_shadow(&s, obj, L, best, dir, &ws);
                     v3 c = phong(s.normal[best_id], o, dir, L, color, ka, ks, sh, best);
                     if (sh_hit) c = v3make(c.x / p->shadow_div, c.y / p->shadow_div, c.z / p->shadow_div);   /* :369 */
-                    sum = v3add(sum, c);                                         /* :370 */
+                    ssum = v3add(ssum, c);                                       /* :370 */
                 }
-                tone = v3make(tone1(sum.x, p->reinhard, p->gamma), tone1(sum.y, p->reinhard, p->gamma), tone1(sum.z, p->reinhard, p->gamma));
-                q[0] = quant1(tone.x); q[1] = quant1(tone.y); q[2] = quant1(tone.z);
             }
+            sum = ss == 0 ? ssum : v3add(sum, ssum);
+            }
+            if (spp > 1) sum = v3make(sum.x / (float)spp, sum.y / (float)spp, sum.z / (float)spp);
+            tone = v3make(tone1(sum.x, p->reinhard, p->gamma), tone1(sum.y, p->reinhard, p->gamma), tone1(sum.z, p->reinhard, p->gamma));
+            q[0] = quant1(tone.x); q[1] = quant1(tone.y); q[2] = quant1(tone.z);
             if (rgb_linear) { rgb_linear[pix * 3] = sum.x; rgb_linear[pix * 3 + 1] = sum.y; rgb_linear[pix * 3 + 2] = sum.z; }
             if (rgb_tone) { rgb_tone[pix * 3] = tone.x; rgb_tone[pix * 3 + 1] = tone.y; rgb_tone[pix * 3 + 2] = tone.z; }
             if (rgb8) {
@@ -311,7 +327,7 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->primary_rays = (uint64_t)W * rows;
+        stats->primary_rays = (uint64_t)W * rows * spp;
         stats->hit_rays = hits;
         stats->shadow_rays = hits * p->n_lights;
         stats->node_tests_primary = node_tests;

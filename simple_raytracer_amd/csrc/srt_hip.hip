@@ -45,6 +45,7 @@ struct srt_scene {
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
+    float* ws_acc = nullptr; float* ws_sub = nullptr; int32_t* ws_sub_hit = nullptr; float* ws_sub_t = nullptr; size_t ws_acc_pixels = 0;
     int n_cu = 256;
     hipEvent_t ev[RING][4] = {};     // start, closest-hit done, shadow done, shade done
     uint32_t ring_count = 0;         // renders since the last srt_sync
@@ -147,6 +148,10 @@ int srt_scene_destroy(srt_scene* s) {
     if (s->ws_lin) (void)hipFree(s->ws_lin);
     if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
     if (s->ws_shadow) (void)hipFree(s->ws_shadow);
+    if (s->ws_acc) (void)hipFree(s->ws_acc);
+    if (s->ws_sub) (void)hipFree(s->ws_sub);
+    if (s->ws_sub_hit) (void)hipFree(s->ws_sub_hit);
+    if (s->ws_sub_t) (void)hipFree(s->ws_sub_t);
     if (s->d_lights) (void)hipFree(s->d_lights);
     if (s->h_lights) (void)hipHostFree(s->h_lights);
     if (s->d_counters) (void)hipFree(s->d_counters);
@@ -283,7 +288,8 @@ uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
-    if (p->spp != 1) return SRT_ERR_ARG;            // spp > 1 is an extension not built yet
+    if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
+    { const uint32_t n = (uint32_t)std::lround(std::sqrt((double)p->spp)); if (n * n != p->spp) return SRT_ERR_ARG; }   // n x n sub-pixel grid
     if (p->flags & SRT_FLAG_SMOOTH_NORMALS) return SRT_ERR_ARG;   // s8 f2, not built yet
     if ((uint64_t)p->width * p->height >= (1ull << 31)) return SRT_ERR_LIMIT;
     if ((uint64_t)p->width * p->height * (p->n_lights ? p->n_lights : 1) >= (1ull << 32)) return SRT_ERR_LIMIT;   // 32-bit work-item index
@@ -317,8 +323,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     if (!d_t) d_t = s->ws_t;
     if (p->n_lights > s->lights_cap) {
         if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
-        if (s->ws_shadow) (void)hipFree(s->ws_shadow);
-    if (s->d_lights) (void)hipFree(s->d_lights);
+        if (s->d_lights) (void)hipFree(s->d_lights);
         if (s->h_lights) (void)hipHostFree(s->h_lights);
         s->d_lights = nullptr; s->h_lights = nullptr; s->lights_cap = 0;
         HIP_TRY(hipMalloc((void**)&s->d_lights, (size_t)p->n_lights * 3 * sizeof(float)));
@@ -343,15 +348,18 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
     dp.i0 = (int)(-(float)p->width / 2); dp.j0 = (int)(-(float)p->height / 2);       // :511,513
+    dp.sub_x = 0.0f; dp.sub_y = 0.0f;                                                 // rayXY = (0, 0), :507,514-515
     dp.focal = p->focal; dp.n_lights = p->n_lights; dp.lights = s->d_lights;
     dp.shadow_div = p->shadow_div; dp.reinhard = p->reinhard; dp.gamma = p->gamma;
     dp.bg = (uint32_t)p->background[0] | ((uint32_t)p->background[1] << 8) | ((uint32_t)p->background[2] << 16);
 
     const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
+    const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);          // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
     const uint32_t variant = (p->flags >> 8) & 0xffu;      // experimental kernel selector (0 = shipped pipeline)
+    const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
-    const size_t shadow_words = (size_t)((p->width + 7) / 8) * ((rows + 7) / 8) * (p->n_lights ? p->n_lights : 1);
+    const size_t shadow_words = (size_t)grid8.x * grid8.y * (p->n_lights ? p->n_lights : 1);
     if (variant != 1 && s->ws_shadow_words < shadow_words) {
         if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
         if (s->ws_shadow) (void)hipFree(s->ws_shadow);
@@ -359,28 +367,43 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         HIP_TRY(hipMalloc((void**)&s->ws_shadow, shadow_words * sizeof(unsigned long long)));
         s->ws_shadow_words = shadow_words;
     }
-    hipEvent_t* ev = s->ev[s->ring_count % RING];
-    HIP_TRY(hipEventRecord(ev[0], stream));
-    if (variant == 1) {                // v0 reference kernels: per-lane walk with inline triangle loop, per-pixel shade
-        if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, ctr);
-        else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, ctr);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[1], stream));
-        HIP_TRY(hipEventRecord(ev[2], stream));
-        if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr, ctr_next);
-        else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr, ctr_next);
-        HIP_TRY(hipGetLastError());
-    } else {
-        const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);      // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
+    if (spp > 1 && s->ws_acc_pixels < pixels) {                    // supersampling extension: accumulation buffers
+        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        if (s->ws_acc) (void)hipFree(s->ws_acc);
+        if (s->ws_sub) (void)hipFree(s->ws_sub);
+        if (s->ws_sub_hit) (void)hipFree(s->ws_sub_hit);
+        if (s->ws_sub_t) (void)hipFree(s->ws_sub_t);
+        s->ws_acc = nullptr; s->ws_sub = nullptr; s->ws_sub_hit = nullptr; s->ws_sub_t = nullptr; s->ws_acc_pixels = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws_acc, pixels * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s->ws_sub, pixels * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&s->ws_sub_hit, pixels * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void**)&s->ws_sub_t, pixels * sizeof(float)));
+        s->ws_acc_pixels = pixels;
+    }
+
+    // One pass of the path over this call's pixels: closest hit (+ shadow rays) and shading.
+    auto launch_frame = [&](const DevParams& fp, int32_t* o_hit, float* o_t, float* o_lin, uint8_t* o_rgb8,
+                            unsigned long long* zero_next, hipEvent_t* ev) -> int {
+        if (variant == 1) {                // v0 reference kernels: per-lane walk with inline triangle loop, per-pixel shade
+            if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, ctr);
+            else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, ctr);
+            HIP_TRY(hipGetLastError());
+            if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
+            if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next);
+            else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next);
+            HIP_TRY(hipGetLastError());
+            return SRT_OK;
+        }
         // closest-hit kernel: CAP = node queue entries, TWL/THL = log2 tile size per wave, FILTER = filtered slab test
         #define LAUNCH_NQ(CAP, TWL, THL, FILTER) do { \
             const dim3 g_((p->width + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
-            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); \
-            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr); } while (0)
+            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); \
+            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); } while (0)
+        const bool fused = (variant == 0 || variant > 10) && p->n_lights;
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
-            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
-            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr);
+            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
+            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
             break;
         case 3: LAUNCH_NQ(160, 2, 2, false); break;      // tiny node queue: exercises the stackless overflow path
         case 4: LAUNCH_NQ(512, 2, 2, false); break;      // shipped geometry with exact divides only
@@ -391,28 +414,54 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         case 9: LAUNCH_NQ(512, 2, 1, true); break;
         case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
         default:                                           // shipped: closest hit + shadow rays fused in one launch
-            if (p->n_lights) {
-                if (count) hipLaunchKernelGGL((k_trace_nq<true, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->ws_shadow, ctr);
-                else       hipLaunchKernelGGL((k_trace_nq<false, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, s->ws_shadow, ctr);
+            if (fused) {
+                if (count) hipLaunchKernelGGL((k_trace_nq<true, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else       hipLaunchKernelGGL((k_trace_nq<false, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }
             break;
         }
         #undef LAUNCH_NQ
-        const bool fused = (variant == 0 || variant > 10) && p->n_lights;
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev[1], stream));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
         if (p->n_lights && !fused) {
-            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else if (variant == 7) hipLaunchKernelGGL((k_shadow_nq<false, 1024, false>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
-            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, ctr);
+            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 7) hipLaunchKernelGGL((k_shadow_nq<false, 1024, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, dp, d_hit_id, d_t, s->ws_shadow, d_rgb_linear, d_rgb8, ctr_next);
+        if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next);
+        HIP_TRY(hipGetLastError());
+        return SRT_OK;
+    };
+
+    hipEvent_t* ev = s->ev[s->ring_count % RING];
+    HIP_TRY(hipEventRecord(ev[0], stream));
+    if (spp == 1) {
+        rc = launch_frame(dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr_next, ev);
+        if (rc != SRT_OK) return rc;
+    } else {
+        // Supersampling (extension): n x n regular sub-pixel grid, offsets (k+0.5)/n - 0.5 added to
+        // dir.xy; the pre-tone-map sums are added in sub-sample order, divided by spp, then tone-mapped once.
+        // hit_id / t report sub-sample 0.  Per-kernel times are those of the last sub-frame.
+        const uint32_t n = (uint32_t)std::lround(std::sqrt((double)spp));
+        const uint32_t gq = (uint32_t)((pixels * 3 + 255) / 256);
+        for (uint32_t k = 0; k < spp; k++) {
+            DevParams fp = dp;
+            fp.sub_x = ((float)(k % n) + 0.5f) / (float)n - 0.5f;
+            fp.sub_y = ((float)(k / n) + 0.5f) / (float)n - 0.5f;
+            rc = launch_frame(fp, k == 0 ? d_hit_id : s->ws_sub_hit, k == 0 ? d_t : s->ws_sub_t, s->ws_sub, nullptr, nullptr,
+                              k == spp - 1 ? ev : nullptr);
+            if (rc != SRT_OK) return rc;
+            hipLaunchKernelGGL(k_accumulate, dim3(gq), block, 0, stream, s->ws_acc, s->ws_sub, (uint32_t)(pixels * 3), k == 0 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((pixels + 255) / 256)), block, 0, stream, dp, s->ws_acc, (float)spp, (uint32_t)pixels,
+                           d_rgb_linear, d_rgb8, ctr_next);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[3], stream));
@@ -420,6 +469,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     s->ring_count++;
     s->last_stream = stream;
     s->pending = true;
+    s->last.primary_rays = (uint64_t)p->width * rows * spp;
     s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
     return SRT_OK;
 }

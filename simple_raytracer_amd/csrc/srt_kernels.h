@@ -31,6 +31,7 @@ struct DevParams {
     uint32_t W, H, rows;
     uint32_t block_rows, block_first, block_stride;
     int32_t i0, j0;
+    float sub_x, sub_y;           // sub-pixel offset added to dir.xy (0 for the reference's one ray per pixel)
     float focal;
     uint32_t n_lights;
     const float* lights;          // device, n_lights x 3
@@ -78,7 +79,7 @@ __device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
 }
 // sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
 __device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
-    return mk((float)(p.i0 + (int)px) + 0.0f, (float)(p.j0 + (int)y) + 0.0f, p.focal);
+    return mk((float)(p.i0 + (int)px) + p.sub_x, (float)(p.j0 + (int)y) + p.sub_y, p.focal);
 }
 
 // =================================================================================================
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
                                                const float* __restrict__ t_in, float* __restrict__ rgb_linear,
                                                uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
                                                unsigned long long* __restrict__ counters_next) {
-    zero_next_counters(counters_next);
+    if (counters_next) zero_next_counters(counters_next);
     uint32_t px, r;
     const bool live = tile_pixel(p, px, r);
     unsigned long long n_node = 0, n_tri = 0;
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
                                                     const unsigned long long* __restrict__ shadow_bits,
                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                     unsigned long long* __restrict__ counters_next) {
-    zero_next_counters(counters_next);
+    if (counters_next) zero_next_counters(counters_next);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t px, r;
     if (!tile_pixel(p, px, r)) return;
@@ -889,6 +890,29 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
     if (rgb8) {
         if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
         rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
+    }
+}
+
+// =================================================================================================
+// Supersampling extension (spp = n x n > 1; not in the reference): the sub-frames' pre-tone-map
+// sums are added in sub-sample order, divided by spp, then tone-mapped / quantised once.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_accumulate(float* __restrict__ acc, const float* __restrict__ sub, uint32_t n, int first) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = first ? sub[i] : acc[i] + sub[i];
+}
+__global__ __launch_bounds__(256) void k_resolve(DevParams p, const float* __restrict__ acc, float spp, uint32_t n_pixels,
+                                                 float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                 unsigned long long* __restrict__ counters_next) {
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < NCTR; i += 256) counters_next[i] = 0ull;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float a0 = acc[(size_t)i * 3] / spp, a1 = acc[(size_t)i * 3 + 1] / spp, a2 = acc[(size_t)i * 3 + 2] / spp;
+    if (rgb_linear) { rgb_linear[(size_t)i * 3] = a0; rgb_linear[(size_t)i * 3 + 1] = a1; rgb_linear[(size_t)i * 3 + 2] = a2; }
+    if (rgb8) {
+        int q0 = quant1(tone1(a0, p.reinhard, p.gamma)), q1 = quant1(tone1(a1, p.reinhard, p.gamma)), q2 = quant1(tone1(a2, p.reinhard, p.gamma));
+        if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }
+        rgb8[(size_t)i * 3] = (uint8_t)q0; rgb8[(size_t)i * 3 + 1] = (uint8_t)q1; rgb8[(size_t)i * 3 + 2] = (uint8_t)q2;
     }
 }
 

@@ -114,6 +114,48 @@ def test_soup_scene_matches_oracle(srt, oracle):
     assert (o["hit_id"] >= 0).sum() > 1000
 
 
+def test_deep_soup_rows_match_oracle(srt, oracle):
+    """200 k triangles (depth-15 trees, ~300 slab tests per ray): a band of scanlines of a 1024x1024 frame
+    against the oracle, all shipped kernels + the overflow-path variant."""
+    import scenes
+    from simple_raytracer_amd import host
+    recipe, meshes = scenes.soup(200000)
+    flat = host.build_flat_scene(recipe, meshes)
+    ds = srt.DeviceScene(flat)
+    kw = dict(block_rows=8, block_first=60, block_stride=10 ** 6)
+    p = abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK, **kw)
+    c = oracle.render(flat, p)
+    assert c["hit_id"].shape[0] == 8 and (c["hit_id"] >= 0).mean() > 0.1
+    for variant in (0, 3):
+        o = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8), **kw))
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+        assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+        check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+        assert o["stats"]["node_tests"] == c["stats"]["node_tests"] and o["stats"]["tri_tests"] == c["stats"]["tri_tests"]
+        o2 = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=variant << 8, **kw))
+        assert np.array_equal(o2["hit_id"], c["hit_id"]) and np.array_equal(bits(o2["rgb_linear"]), bits(o["rgb_linear"]))
+
+
+@pytest.mark.parametrize("name,W,H,L,spp", [("cubes4_a0", 128, 96, 3, 4), ("ground_bunny", 96, 54, 1, 9), ("texquad", 64, 48, 2, 16)])
+def test_supersampling_extension_matches_oracle(srt, oracle, name, W, H, L, spp):
+    """spp > 1 does not exist in the reference: pinned by the oracle's restatement of the same
+    definition only (regular n x n sub-pixel grid, sums averaged before tone mapping)."""
+    g, ds = device_scene(srt, name)
+    p = g.params(W, H, L, spp=spp, flags=abi.SRT_FLAG_COUNT_WORK)
+    o = ds.render(p); c = oracle.render(g.flat, p)
+    assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+    for k in ("primary_rays", "hit_rays", "shadow_rays", "node_tests", "tri_tests"):
+        assert o["stats"][k] == c["stats"][k], k
+    assert o["stats"]["primary_rays"] == W * H * spp
+    # spp = 1 through the same entry point is still the reference's image
+    o1 = ds.render(g.params(W, H, L))
+    assert np.array_equal(o1["hit_id"], g.out(W, H, L, "hit_id")) if g.out(W, H, L, "hit_id") is not None else True
+    with pytest.raises(srt.SrtError):
+        ds.render(g.params(W, H, L, spp=3))           # not a square grid
+
+
 def test_bad_scene_is_rejected_not_faulted(srt):
     g, _ = device_scene(srt, "cube")
     import copy
@@ -126,7 +168,7 @@ def test_bad_scene_is_rejected_not_faulted(srt):
     f.node_first = f.node_first.copy(); f.node_first[2] = 0        # leaves not contiguous in visit order
     with pytest.raises(srt.SrtError):
         srt.DeviceScene(f)
-    p = g.params(64, 64, 1); p.spp = 4
+    p = g.params(64, 64, 1); p.spp = 5
     _, ds = device_scene(srt, "cube")
     with pytest.raises(srt.SrtError):
         ds.render(p)

@@ -114,3 +114,20 @@ def test_oracle_vs_live_reference_random_scenes(oracle):
         assert np.array_equal(o["hit_id"], hit)
         assert np.array_equal(bits(o["t"]), bits(t)) and np.array_equal(bits(o["rgb_linear"]), bits(lin))
         assert np.array_equal(bits(o["rgb_tone"]), bits(tone))
+
+
+def test_supersampling_extension_definition(oracle):
+    """spp = n x n (extension): sub-sample 0 of a 2x2 grid is the frame rendered with a -0.25 px offset; the
+    pixel is the tone-mapped mean of the four sub-frames' pre-tone-map sums."""
+    g = gu.GoldenScene("cubes4_a0")
+    W, H, L = 64, 48, 2
+    o4 = oracle.render(g.flat, g.params(W, H, L, spp=4))
+    assert o4["stats"]["primary_rays"] == W * H * 4 and o4["stats"]["shadow_rays"] == o4["stats"]["hit_rays"] * L
+    o1 = oracle.render(g.flat, g.params(W, H, L))
+    assert np.array_equal(o1["hit_id"], oracle.render(g.flat, g.params(W, H, L, spp=1))["hit_id"])
+    # an interior pixel of a flat face has the same hit in all four sub-samples -> nearly the 1-spp value
+    same = (o4["hit_id"] == o1["hit_id"]) & (o1["hit_id"] >= 0)
+    assert same.mean() > 0.05
+    assert np.median(np.abs(o4["rgb_linear"][same] - o1["rgb_linear"][same])) < 1e-3
+    with pytest.raises(RuntimeError):
+        oracle.render(g.flat, g.params(W, H, L, spp=2))
