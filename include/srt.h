@@ -81,7 +81,10 @@ typedef struct srt_scene_desc {
 /* ---- render parameters: every compile-time literal of the reference path, as data -------------- */
 enum {
     SRT_FLAG_NONE           = 0,
-    SRT_FLAG_SMOOTH_NORMALS = 1u << 0,  /* interpolateNormal (simple_raytracer.cpp:132-140,162)     */
+    SRT_FLAG_SMOOTH_NORMALS = 1u << 0,  /* interpolateNormal (simple_raytracer.cpp:132-140) instead of the flat face
+                                         * normal: the line the reference keeps commented out at :162; needs
+                                         * srt_scene_desc.tri_normals.  The function is pinned by a reference KAT,
+                                         * the images only by the oracle (the reference cannot render this mode) */
     SRT_FLAG_COUNT_WORK     = 1u << 1   /* run the counting build: fills node/tri test counters      */
 };
 
@@ -177,6 +180,7 @@ int srt_kat_ray_aabb(int device, uint32_t n, const float* ray_od, const float* b
                      uint8_t* filtered, uint8_t* ambiguous);
 int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const float* tri_points, float* t);
 int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb);
+int srt_kat_interp_normal(int device, uint32_t n, const float* in12 /* 3 normals + barycentrics */, float* out3);   /* interpolateNormal :132-140 */
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q);
 
 const char* srt_strerror(int code);

@@ -340,3 +340,13 @@ def ref_kat_tonemap(lin):
     L = ref_lib(); lin = np.ascontiguousarray(lin, np.float32).reshape(-1, 3); n = lin.shape[0]
     tone = np.empty((n, 3), np.float32); q = np.empty((n, 3), np.int32)
     L.ref_kat_tonemap(C.c_uint32(n), _p(lin, _f32p), _p(tone, _f32p), _p(q, _i32p)); return tone, q
+
+
+def ref_kat_interp_normal(inp):
+    L = ref_lib(); inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; out = np.empty((n, 3), np.float32)
+    L.ref_kat_interp_normal(C.c_uint32(n), _p(inp, _f32p), _p(out, _f32p)); return out
+
+
+def interp_normal(inp):
+    L = oracle_lib(); inp = np.ascontiguousarray(inp, np.float32); n = inp.shape[0]; out = np.empty((n, 3), np.float32)
+    L.oracle_interp_normal(C.c_uint32(n), _p(inp, _f32p), _p(out, _f32p)); return out

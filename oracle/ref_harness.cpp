@@ -299,6 +299,15 @@ void ref_kat_barycentric(uint32_t n, const float* in /* n x 15 */, float* uvw) {
         uvw[i*3] = b.x; uvw[i*3+1] = b.y; uvw[i*3+2] = b.z;
     }
 }
+// interpolateNormal (:132-140; its call at :162 is commented out in the reference): in = 3 vertex normals (9) + barycentrics (3)
+void ref_kat_interp_normal(uint32_t n, const float* in /* n x 12 */, float* out /* n x 3 */) {
+    for (uint32_t i = 0; i < n; i++) {
+        const float* p = in + (size_t)i * 12;
+        Triangle T(glm::vec4(0), glm::vec4(0), glm::vec4(0), glm::vec3(p[0], p[1], p[2]), glm::vec3(p[3], p[4], p[5]), glm::vec3(p[6], p[7], p[8]));
+        glm::vec3 r = interpolateNormal(T, glm::vec3(p[9], p[10], p[11]));
+        out[i*3] = r.x; out[i*3+1] = r.y; out[i*3+2] = r.z;
+    }
+}
 // Reinhard + gamma tail of softShadow (:391-398) and the quantiser of rayIntersection (:447-449)
 void ref_kat_tonemap(uint32_t n, const float* lin /* n x 3 */, float* tone, int32_t* q) {
     for (uint32_t i = 0; i < n; i++) {

@@ -100,6 +100,14 @@ static inline v3 face_normal(const float* p) {
     return normalize3(cross3(a, b));
 }
 
+/* ---- interpolateNormal :132-140 (smooth shading; the reference's call at :162 is commented out, so this is
+ * the opt-in SRT_FLAG_SMOOTH_NORMALS mode): normalize(bc.x*n1 + bc.y*n2 + bc.z*n3) */
+static inline v3 interp_normal(const float* n9, v3 bc) {
+    v3 n = v3make((bc.x * n9[0] + bc.y * n9[3]) + bc.z * n9[6], (bc.x * n9[1] + bc.y * n9[4]) + bc.z * n9[7],
+                  (bc.x * n9[2] + bc.y * n9[5]) + bc.z * n9[8]);
+    return normalize3(n);
+}
+
 /* ---- a8: phongIllumination :144-200 (lightColor = (1,1,1), :433) ------------------------------ */
 static inline v3 phong(v3 n, v3 o, v3 d, v3 L, v3 objColor, float ka, float ks, float shin, float t) {
     const float rView = 1.0f / 3.14159265358979323846264338327950288f;   /* :153, glm::pi<float>() */
@@ -236,6 +244,8 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     const uint32_t spp = p->spp, spp_n = (uint32_t)lroundf(sqrtf((float)p->spp));
     if (spp < 1 || spp_n * spp_n != spp) return SRT_ERR_ARG;      /* supersampling extension: n x n sub-pixel grid */
+    const int smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) != 0;
+    if (smooth && !d->tri_normals) return SRT_ERR_ARG;
     scene_view s; s.d = d;
     s.geom = (tri_geom*)malloc(sizeof(tri_geom) * (d->n_tris ? d->n_tris : 1));
     s.normal = (v3*)malloc(sizeof(v3) * (d->n_tris ? d->n_tris : 1));
@@ -301,10 +311,15 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                     color = v3make(td[texIndex] / 255.0f, td[texIndex + 1] / 255.0f, td[texIndex + 2] / 255.0f);
                 }
                 const float ka = d->obj_material[obj * 3], ks = d->obj_material[obj * 3 + 1], sh = d->obj_material[obj * 3 + 2];
+                v3 nrm = s.normal[best_id];
+                if (smooth) {       /* phongIllumination:159,162 with the interpolateNormal line enabled */
+                    v3 P = v3add(o, v3scale(dir, best));
+                    nrm = interp_normal(d->tri_normals + 9 * (size_t)best_id, barycentric(&s.geom[best_id], P));
+                }
                 for (uint32_t l = 0; l < p->n_lights; l++) {                    /* softShadow:366-383 */
                     v3 L = v3make(p->light_pos[l * 3], p->light_pos[l * 3 + 1], p->light_pos[l * 3 + 2]);
                     int sh_hit = in_shadow(&s, obj, L, best, dir, &ws);
-                    v3 c = phong(s.normal[best_id], o, dir, L, color, ka, ks, sh, best);
+                    v3 c = phong(nrm, o, dir, L, color, ka, ks, sh, best);
                     if (sh_hit) c = v3make(c.x / p->shadow_div, c.y / p->shadow_div, c.z / p->shadow_div);   /* :369 */
                     ssum = v3add(ssum, c);                                       /* :370 */
                 }
@@ -368,6 +383,13 @@ void oracle_barycentric(uint32_t n, const float* in, float* uvw) {
         tri_geom g = tri_geom_from_points(p);
         v3 b = barycentric(&g, v3make(p[12], p[13], p[14]));
         uvw[i * 3] = b.x; uvw[i * 3 + 1] = b.y; uvw[i * 3 + 2] = b.z;
+    }
+}
+void oracle_interp_normal(uint32_t n, const float* in12, float* out3) {
+    for (uint32_t i = 0; i < n; i++) {
+        const float* q = in12 + 12 * (size_t)i;
+        v3 r = interp_normal(q, v3make(q[9], q[10], q[11]));
+        out3[i * 3] = r.x; out3[i * 3 + 1] = r.y; out3[i * 3 + 2] = r.z;
     }
 }
 void oracle_tonemap(uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q) {

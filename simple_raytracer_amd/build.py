@@ -72,8 +72,27 @@ def build_host(force=False, verbose=False):
     return LIB_HOST
 
 
+EXAMPLE_ORBIT = os.path.join(HERE, "..", "examples", "orbit")
+
+
+def build_examples(force=False, verbose=False):
+    """examples/orbit: a scene script in the shape of the reference's main(), on the host mirror."""
+    src = os.path.join(HERE, "..", "examples", "orbit.cpp")
+    if not force and not _stale(EXAMPLE_ORBIT, [src, LIB_HOST]):
+        return EXAMPLE_ORBIT
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-o", EXAMPLE_ORBIT, src,
+           "-L" + HERE, "-lsrt_host", "-lsrt_hip", "-Wl,-rpath,$ORIGIN/../simple_raytracer_amd"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed for examples/orbit")
+    return EXAMPLE_ORBIT
+
+
 def build_all(force=False, verbose=False):
-    return [build_hip(force, verbose), build_host(force, verbose)]
+    return [build_hip(force, verbose), build_host(force, verbose), build_examples(force, verbose)]
 
 
 if __name__ == "__main__":

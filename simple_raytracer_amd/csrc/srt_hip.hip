@@ -251,6 +251,7 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     UP(upload(s, ranges.data(), ranges.size(), &s->dev.obj_range));
     UP(upload(s, d->obj_color, (size_t)d->n_objects * 3, &s->dev.obj_color));
     UP(upload(s, d->obj_material, (size_t)d->n_objects * 3, &s->dev.obj_mat));
+    if (d->tri_normals && d->n_tris) UP(upload(s, d->tri_normals, (size_t)d->n_tris * 9, &s->dev.tri_normals));
     bool any_tex = false;
     if (d->n_textures && d->tri_tex) for (uint32_t i = 0; i < d->n_tris; i++) any_tex |= d->tri_tex[i] >= 0;
     if (any_tex) {
@@ -285,12 +286,13 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
 
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
 
+static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) & 0xffu; }
+
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
     { const uint32_t n = (uint32_t)std::lround(std::sqrt((double)p->spp)); if (n * n != p->spp) return SRT_ERR_ARG; }   // n x n sub-pixel grid
-    if (p->flags & SRT_FLAG_SMOOTH_NORMALS) return SRT_ERR_ARG;   // s8 f2, not built yet
     if ((uint64_t)p->width * p->height >= (1ull << 31)) return SRT_ERR_LIMIT;
     if ((uint64_t)p->width * p->height * (p->n_lights ? p->n_lights : 1) >= (1ull << 32)) return SRT_ERR_LIMIT;   // 32-bit work-item index
     return SRT_OK;
@@ -344,7 +346,9 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     s->render_seq++;
     s->d_ctr_last = ctr;
 
+    if ((p->flags & SRT_FLAG_SMOOTH_NORMALS) && (!s->dev.tri_normals || variant_of(p) == 1)) return SRT_ERR_ARG;   // needs vertex normals
     DevParams dp;
+    dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
     dp.i0 = (int)(-(float)p->width / 2); dp.j0 = (int)(-(float)p->height / 2);       // :511,513
@@ -586,6 +590,16 @@ int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb) {
     hipLaunchKernelGGL(k_kat_phong, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, (const DevTri*)q.p, (float*)o.p);
     HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     return o.down(rgb, (size_t)n * 12);
+}
+
+int srt_kat_interp_normal(int device, uint32_t n, const float* in12, float* out3) {
+    if (!n || !in12 || !out3) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf a, o;
+    KAT_TRY(a.up(in12, (size_t)n * 48)); KAT_TRY(o.alloc((size_t)n * 12));
+    hipLaunchKernelGGL(k_kat_interp_normal, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, (float*)o.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    return o.down(out3, (size_t)n * 12);
 }
 
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q) {

@@ -16,6 +16,7 @@ struct DevScene {
     const int32_t* tri_obj;
     const int32_t* tri_tex;       // may be null (no textures)
     const float* tri_tc;          // n_tris x 6, may be null
+    const float* tri_normals;     // n_tris x 9 vertex normals, may be null (SRT_FLAG_SMOOTH_NORMALS only)
     const float* obj_color;       // n_objects x 3
     const float* obj_mat;         // n_objects x 3
     const int2* obj_range;        // n_objects: [first node, end node) in pre-order
@@ -37,6 +38,7 @@ struct DevParams {
     const float* lights;          // device, n_lights x 3
     float shadow_div, reinhard, gamma;
     uint32_t bg;                  // r | g << 8 | b << 16
+    uint32_t smooth;              // interpolateNormal mode (simple_raytracer.cpp:132-140,162)
 };
 
 // counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
@@ -874,12 +876,20 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
         color = mk(td[0] / 255.0f, td[1] / 255.0f, td[2] / 255.0f);
     }
     const float ka = s.obj_mat[obj * 3], ks = s.obj_mat[obj * 3 + 1], sh = s.obj_mat[obj * 3 + 2];
+    V3 nrm_use = nrm;
+    if (p.smooth) {        // phongIllumination:159,162 with the interpolateNormal line enabled (opt-in mode)
+        const float4 t0 = tp[0], t1 = tp[1];
+        const V3 bc = barycentric(mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, t2.x), o + d * t);
+        const float* n9 = s.tri_normals + (size_t)id * 9;
+        nrm_use = normalize3(mk((bc.x * n9[0] + bc.y * n9[3]) + bc.z * n9[6], (bc.x * n9[1] + bc.y * n9[4]) + bc.z * n9[7],
+                                (bc.x * n9[2] + bc.y * n9[5]) + bc.z * n9[8]));
+    }
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     const unsigned long long* sb = shadow_bits + tile_index * p.n_lights;
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
         const bool shadowed = (sb[l] >> lane) & 1ull;
-        V3 c = phong(nrm, o, d, L, color, ka, ks, sh, t);
+        V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
         if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
         sum = sum + c;                                                                          // :370
     }
@@ -947,6 +957,14 @@ __global__ void k_kat_phong(uint32_t n, const float* __restrict__ in, const DevT
     const V3 c = phong(mk(tr.nx, tr.ny, tr.nz), mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5]), mk(q[18], q[19], q[20]),
                        mk(q[21], q[22], q[23]), q[24], q[25], q[26], q[27]);
     rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+}
+__global__ void k_kat_interp_normal(uint32_t n, const float* __restrict__ in12, float* __restrict__ out3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = in12 + 12 * (size_t)i;
+    const V3 r = normalize3(mk((q[9] * q[0] + q[10] * q[3]) + q[11] * q[6], (q[9] * q[1] + q[10] * q[4]) + q[11] * q[7],
+                               (q[9] * q[2] + q[10] * q[5]) + q[11] * q[8]));
+    out3[i * 3] = r.x; out3[i * 3 + 1] = r.y; out3[i * 3 + 2] = r.z;
 }
 __global__ void k_kat_tonemap(uint32_t n, const float* __restrict__ lin, float reinhard, float gamma, float* __restrict__ tone, int32_t* __restrict__ q) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

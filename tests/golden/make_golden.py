@@ -274,6 +274,13 @@ def make_kat():
     d["tf_mul"] = np.stack([M.mul(d["tf_view"][i], d["tf_view"][(i + 1) % 10]) for i in range(10)])
     v4 = np.concatenate([rng.uniform(-500, 500, (10, 3)), np.ones((10, 1))], 1).astype(np.float32)
     d["tf_vec"] = v4; d["tf_mulvec"] = np.stack([M.mul_vec4(d["tf_view_inv"][i], v4[i]) for i in range(10)])
+    # ---- interpolateNormal (:132-140), drawn AFTER everything above so that earlier vectors keep their values ----
+    nin = np.zeros((256, 12), np.float32)
+    nv = rng.normal(0, 1, (256, 3, 3)).astype(np.float32)
+    nv /= np.linalg.norm(nv, axis=2, keepdims=True).astype(np.float32)
+    nin[:, :9] = nv.reshape(256, 9); nin[:, 9:] = rng.dirichlet([1, 1, 1], 256).astype(np.float32)
+    nin[:8, :9] = 0.0                                   # missing normals (loader default 0): 0 * inf -> NaN
+    d["in_in"] = nin; d["in_out"] = po.ref_kat_interp_normal(nin)
     np.savez_compressed(os.path.join(HERE, "kat.npz"), **d)
     print("kat.npz", os.path.getsize(os.path.join(HERE, "kat.npz")) // 1024, "KiB")
 

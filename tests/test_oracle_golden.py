@@ -43,6 +43,11 @@ def test_kat_barycentric(oracle, kat):
     assert np.array_equal(bits(oracle.barycentric(kat["bc_in"])), bits(kat["bc_uvw"]))
 
 
+def test_kat_interp_normal(oracle, kat):
+    assert np.array_equal(bits(oracle.interp_normal(kat["in_in"])), bits(kat["in_out"]))
+    assert np.isnan(kat["in_out"][:8]).all()          # missing normals (0,0,0): 0 * (1/sqrt(0)) = NaN, as the reference
+
+
 def test_kat_tonemap(oracle, kat):
     tone, q = oracle.tonemap(kat["tm_lin"])
     assert np.array_equal(bits(tone), bits(kat["tm_tone"]))
