@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 logic on a box with fewer "
                          "GPUs than ranks (ranks share devices, tiles are staged through host memory)")
@@ -71,7 +72,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    build.build_all()
+    # only one process compiles (ranks share the source tree); the others wait for it
+    if rank == 0:
+        build.build_all()
+    if world > 1:
+        dist.barrier()
     lib.load()
 
     W, H, L, B = args.width, args.height, args.lights, args.frames
@@ -95,12 +100,34 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
+    def render_frames(pp):
+        for f in range(B):
+            scene.render_device(pp, stream=torch.cuda.current_stream().cuda_stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(),
+                                rgb_linear=lin.data_ptr(), rgb8=gather.tile.data_ptr() + f * frame_bytes)
+
+    # The B renders of a step are launch-bound when a rank owns 1/8 of a frame: capture them once into a hipGraph
+    # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
+    graph = None
+    if not args.no_graph and B % 2 == 0:
+        p_quiet = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING)
+        try:
+            render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                render_frames(p_quiet)
+        except Exception as e:                                         # capture is an optimisation, not a requirement
+            if rank == 0:
+                print(f"bench: hipGraph capture unavailable ({e}); eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
     def step():
         # one step = B frames (the reference's main() renders a 36-frame orbit per run, simple_raytracer.cpp:534):
         # every rank renders its scanline blocks of each frame, then ONE gather moves all B tiles to rank 0
-        for f in range(B):
-            scene.render_device(p, stream=stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(), rgb_linear=lin.data_ptr(),
-                                rgb8=gather.tile.data_ptr() + f * frame_bytes)
+        if graph is not None:
+            graph.replay()
+        else:
+            render_frames(p)
         if world > 1:
             gather.gather()
 
@@ -112,17 +139,21 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    scene.sync()                      # drop warmup launches from the kernel-time average
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    st = scene.sync()                 # HIP-event kernel times averaged over (up to 64 of) the timed launches
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # per-kernel durations: HIP events on the launch stream over B eager renders of the same frames (the events of
+    # a captured graph cannot be read back), averaged by srt_sync
+    scene.sync()
+    render_frames(p)
+    torch.cuda.synchronize()
+    st = scene.sync()
     rgb8 = gather.tile[0]
 
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
@@ -177,7 +208,7 @@ def main():
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
                        "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step",
-                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5),
+                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5), "launch": "hipGraph replay" if graph is not None else "eager",
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,

@@ -85,7 +85,9 @@ enum {
                                          * normal: the line the reference keeps commented out at :162; needs
                                          * srt_scene_desc.tri_normals.  The function is pinned by a reference KAT,
                                          * the images only by the oracle (the reference cannot render this mode) */
-    SRT_FLAG_COUNT_WORK     = 1u << 1   /* run the counting build: fills node/tri test counters      */
+    SRT_FLAG_COUNT_WORK     = 1u << 1,  /* run the counting build: fills node/tri test counters      */
+    SRT_FLAG_NO_TIMING      = 1u << 2   /* record no HIP events: for launches captured into a hipGraph (an even number
+                                         * of renders per graph keeps the two alternating counter sets in step)     */
 };
 
 typedef struct srt_params {

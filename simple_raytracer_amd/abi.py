@@ -13,6 +13,7 @@ import numpy as np
 SRT_OK = 0
 SRT_FLAG_SMOOTH_NORMALS = 1 << 0
 SRT_FLAG_COUNT_WORK = 1 << 1
+SRT_FLAG_NO_TIMING = 1 << 2
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -138,10 +138,16 @@ uint32_t srt_rows_owned(const srt_params* p) {
     return rows;
 }
 
+// Wait for the work of earlier renders before their buffers are reused or freed.
+static hipError_t wait_idle(srt_scene* s) {
+    if (!s->pending) return hipSuccess;
+    return s->last_done ? hipEventSynchronize(s->last_done) : hipStreamSynchronize(s->last_stream);
+}
+
 int srt_scene_destroy(srt_scene* s) {
     if (!s) return SRT_ERR_ARG;
     (void)hipSetDevice(s->device);
-    if (s->pending) (void)hipEventSynchronize(s->last_done);
+    (void)wait_idle(s);
     for (void* d : s->allocs) (void)hipFree(d);
     if (s->ws_hit) (void)hipFree(s->ws_hit);
     if (s->ws_t) (void)hipFree(s->ws_t);
@@ -313,7 +319,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     const size_t pixels = (size_t)p->width * rows;
     // workspace for hit ids / t when the caller does not want them (the shade kernel does)
     if ((!d_hit_id || !d_t) && s->ws_pixels < pixels) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        HIP_TRY(wait_idle(s));
         if (s->ws_hit) (void)hipFree(s->ws_hit);
         if (s->ws_t) (void)hipFree(s->ws_t);
         s->ws_hit = nullptr; s->ws_t = nullptr; s->ws_pixels = 0;
@@ -324,7 +330,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     if (!d_hit_id) d_hit_id = s->ws_hit;
     if (!d_t) d_t = s->ws_t;
     if (p->n_lights > s->lights_cap) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        HIP_TRY(wait_idle(s));
         if (s->d_lights) (void)hipFree(s->d_lights);
         if (s->h_lights) (void)hipHostFree(s->h_lights);
         s->d_lights = nullptr; s->h_lights = nullptr; s->lights_cap = 0;
@@ -334,7 +340,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     }
     const size_t light_bytes = (size_t)p->n_lights * 3 * sizeof(float);
     if (p->n_lights && !(s->lights_valid == p->n_lights && std::memcmp(s->h_lights, p->light_pos, light_bytes) == 0)) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));     // staging buffer still in flight
+        HIP_TRY(wait_idle(s));     // staging buffer still in flight
         std::memcpy(s->h_lights, p->light_pos, light_bytes);
         HIP_TRY(hipMemcpyAsync(s->d_lights, s->h_lights, light_bytes, hipMemcpyHostToDevice, stream));
         s->lights_valid = p->n_lights;
@@ -365,14 +371,14 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     const size_t shadow_words = (size_t)grid8.x * grid8.y * (p->n_lights ? p->n_lights : 1);
     if (variant != 1 && s->ws_shadow_words < shadow_words) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        HIP_TRY(wait_idle(s));
         if (s->ws_shadow) (void)hipFree(s->ws_shadow);
         s->ws_shadow = nullptr; s->ws_shadow_words = 0;
         HIP_TRY(hipMalloc((void**)&s->ws_shadow, shadow_words * sizeof(unsigned long long)));
         s->ws_shadow_words = shadow_words;
     }
     if (spp > 1 && s->ws_acc_pixels < pixels) {                    // supersampling extension: accumulation buffers
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        HIP_TRY(wait_idle(s));
         if (s->ws_acc) (void)hipFree(s->ws_acc);
         if (s->ws_sub) (void)hipFree(s->ws_sub);
         if (s->ws_sub_hit) (void)hipFree(s->ws_sub_hit);
@@ -443,8 +449,9 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         return SRT_OK;
     };
 
-    hipEvent_t* ev = s->ev[s->ring_count % RING];
-    HIP_TRY(hipEventRecord(ev[0], stream));
+    // SRT_FLAG_NO_TIMING: no event records (a caller capturing the launches into a hipGraph)
+    hipEvent_t* ev = (p->flags & SRT_FLAG_NO_TIMING) ? nullptr : s->ev[s->ring_count % RING];
+    if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (spp == 1) {
         rc = launch_frame(dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr_next, ev);
         if (rc != SRT_OK) return rc;
@@ -459,7 +466,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
             fp.sub_x = ((float)(k % n) + 0.5f) / (float)n - 0.5f;
             fp.sub_y = ((float)(k / n) + 0.5f) / (float)n - 0.5f;
             rc = launch_frame(fp, k == 0 ? d_hit_id : s->ws_sub_hit, k == 0 ? d_t : s->ws_sub_t, s->ws_sub, nullptr, nullptr,
-                              k == spp - 1 ? ev : nullptr);
+                              (k == spp - 1) ? ev : nullptr);
             if (rc != SRT_OK) return rc;
             hipLaunchKernelGGL(k_accumulate, dim3(gq), block, 0, stream, s->ws_acc, s->ws_sub, (uint32_t)(pixels * 3), k == 0 ? 1 : 0);
             HIP_TRY(hipGetLastError());
@@ -468,9 +475,13 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
                            d_rgb_linear, d_rgb8, ctr_next);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(ev[3], stream));
-    s->last_done = ev[3];
-    s->ring_count++;
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev[3], stream));
+        s->last_done = ev[3];
+        s->ring_count++;
+    } else {
+        s->last_done = nullptr;
+    }
     s->last_stream = stream;
     s->pending = true;
     s->last.primary_rays = (uint64_t)p->width * rows * spp;
@@ -485,6 +496,7 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         const uint32_t n = s->ring_count < RING ? s->ring_count : RING;
         double a = 0., b = 0., c = 0., sh = 0.;
+        if (n == 0) { s->last.ms_primary = s->last.ms_shadow = s->last.ms_shade = s->last.ms_total = 0.f; }
         for (uint32_t k = 0; k < n; k++) {
             hipEvent_t* ev = s->ev[(s->ring_count - 1 - k) % RING];
             float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
@@ -494,8 +506,10 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
             HIP_TRY(hipEventElapsedTime(&z, ev[0], ev[3]));
             a += x; b += y; c += z; sh += w;
         }
-        s->last.ms_primary = (float)(a / n); s->last.ms_shadow = (float)(b / n); s->last.ms_shade = (float)(sh / n);
-        s->last.ms_total = (float)(c / n);
+        if (n) {
+            s->last.ms_primary = (float)(a / n); s->last.ms_shadow = (float)(b / n); s->last.ms_shade = (float)(sh / n);
+            s->last.ms_total = (float)(c / n);
+        }
         s->last.launches = n;
         s->ring_count = 0;
         HIP_TRY(hipMemcpy(s->h_counters, s->d_ctr_last, NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -521,7 +535,7 @@ int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, flo
     const uint32_t rows = srt_rows_owned(p);
     const size_t pixels = (size_t)p->width * rows;
     if (pixels > s->ws_out_pixels) {
-        if (s->pending) HIP_TRY(hipEventSynchronize(s->last_done));
+        HIP_TRY(wait_idle(s));
         if (s->ws_lin) (void)hipFree(s->ws_lin);
         if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
         s->ws_lin = nullptr; s->ws_rgb8 = nullptr; s->ws_out_pixels = 0;
