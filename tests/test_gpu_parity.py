@@ -343,3 +343,30 @@ def test_smooth_normal_mode(srt, oracle):
     _, ds0 = device_scene(srt, "cube")               # scene without normals: the mode is refused, not guessed
     with pytest.raises(srt.SrtError):
         ds0.render(abi.make_params(32, 32, [g.light], flags=abi.SRT_FLAG_SMOOTH_NORMALS))
+
+
+def test_many_objects_empty_objects_and_no_lights(srt, oracle):
+    """40 objects (root pairs are queued in groups of 16), one of them empty (the reference's failed-load case:
+    two empty leaves with inverted boxes), one with a single triangle; n_lights = 0 gives black = background."""
+    import scenes
+    from simple_raytracer_amd import host
+    recipe, meshes = scenes.soup(4000, n_objects=38)
+    meshes["none"] = np.zeros((0, 3, 4), np.float32)
+    meshes["one"] = np.array([[[-30, -30, 200, 1], [30, -30, 200, 1], [0, 40, 210, 1]]], np.float32)
+    recipe.load("empty.obj", "none"); recipe.bvh("empty.obj")
+    recipe.load("single.obj", "one"); recipe.color("single.obj", (0.2, 0.9, 0.9)); recipe.bvh("single.obj")
+    flat = host.build_flat_scene(recipe, meshes)
+    assert flat.n_objects == 40 and 0 in list(flat.node_count[flat.node_left < 0])
+    ds = srt.DeviceScene(flat)
+    for variant in (0, 3, 10):
+        p = abi.make_params(203, 117, abi.light_staircase(recipe.light, 2), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
+        o = ds.render(p); c = oracle.render(flat, p)
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+        assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+        check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+        assert o["stats"]["node_tests"] == c["stats"]["node_tests"] and o["stats"]["tri_tests"] == c["stats"]["tri_tests"]
+    assert (c["hit_id"] >= 0).sum() > 300
+    p0 = abi.make_params(64, 64, np.zeros((0, 3), np.float32))
+    o0 = ds.render(p0); c0 = oracle.render(flat, p0)
+    assert np.array_equal(o0["hit_id"], c0["hit_id"]) and np.array_equal(o0["rgb8"], c0["rgb8"])
+    assert np.all(o0["rgb8"] == np.array(abi.REFERENCE_BACKGROUND, np.uint8)) and not o0["rgb_linear"].any()
