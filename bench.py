@@ -95,53 +95,61 @@ def main():
     lin = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
+    SLOTS = 2 if world > 1 else 1        # double-buffered tiles: the gather of step s overlaps the rendering of step s+1
     gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B,
-                                stage_through_host=(args.backend == "gloo"))
+                                stage_through_host=(args.backend == "gloo"), slots=SLOTS)
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
-    def render_frames(pp):
+    def render_frames(pp, slot=0):
         for f in range(B):
             scene.render_device(pp, stream=torch.cuda.current_stream().cuda_stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(),
-                                rgb_linear=lin.data_ptr(), rgb8=gather.tile.data_ptr() + f * frame_bytes)
+                                rgb_linear=lin.data_ptr(), rgb8=gather.tiles[slot].data_ptr() + f * frame_bytes)
 
     # The B renders of a step are launch-bound when a rank owns 1/8 of a frame: capture them once into a hipGraph
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
-    graph = None
+    graphs = None
     if not args.no_graph and B % 2 == 0:
         p_quiet = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING)
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                render_frames(p_quiet)
+            graphs = []
+            for slot in range(SLOTS):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    render_frames(p_quiet, slot)
+                graphs.append(gph)
         except Exception as e:                                         # capture is an optimisation, not a requirement
             if rank == 0:
                 print(f"bench: hipGraph capture unavailable ({e}); eager launches", file=sys.stderr)
-            graph = None
+            graphs = None
             torch.cuda.synchronize()
+    graph = graphs
 
-    def step():
+    def step(i):
         # one step = B frames (the reference's main() renders a 36-frame orbit per run, simple_raytracer.cpp:534):
-        # every rank renders its scanline blocks of each frame, then ONE gather moves all B tiles to rank 0
-        if graph is not None:
-            graph.replay()
+        # every rank renders its scanline blocks of each frame, then ONE gather moves all B tiles to rank 0.  With
+        # two tile slots the gather of step i runs on RCCL's stream while step i+1 renders into the other slot.
+        slot = i % SLOTS
+        gather.finish(slot)              # the gather that used this slot two steps ago (rank 0 de-interleaves it)
+        if graphs is not None:
+            graphs[slot].replay()
         else:
-            render_frames(p)
-        if world > 1:
-            gather.gather()
+            render_frames(p, slot)
+        gather.start(slot)
 
     def fence():
+        gather.finish_all()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -154,7 +162,7 @@ def main():
     render_frames(p)
     torch.cuda.synchronize()
     st = scene.sync()
-    rgb8 = gather.tile[0]
+    rgb8 = gather.tiles[0][0]
 
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
@@ -207,7 +215,7 @@ def main():
                        "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
-                       "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step",
+                       "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step, overlapped with the next step's rendering",
                        "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5), "launch": "hipGraph replay" if graph is not None else "eager",
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

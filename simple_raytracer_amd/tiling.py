@@ -17,12 +17,23 @@ from . import abi
 
 
 class FrameGather:
-    """Owns this rank's padded output tile and assembles the whole frame on rank `dst`.
+    """Owns this rank's padded output tiles and assembles whole frames on rank `dst`.
 
-    Every rank's tile is padded to the same number of rows so that the exchange is ONE equal-size
-    gather per frame (7 peers -> rank 0, each over its own xGMI link)."""
+    Every rank's tile is padded to the same number of rows so that the exchange is ONE equal-size gather per
+    step (7 peers -> rank 0, each over its own xGMI link).  `slots` > 1 gives that many independent tile buffers so
+    that the gather of one step overlaps the rendering of the next (RCCL runs the collective on its own stream):
 
-    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1, stage_through_host=False):
+        g = FrameGather(..., frames=B, slots=2)
+        for step in range(K):
+            k = step % 2
+            g.finish(k)                  # the gather that last used slot k is done; rank dst de-interleaves it
+            render into g.tiles[k] ...
+            g.start(k)                   # asynchronous gather of slot k
+        g.finish_all()
+    """
+
+    def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1,
+                 stage_through_host=False, slots=1):
         self.W, self.H, self.block_rows, self.rank, self.world, self.dst = width, height, block_rows, rank, world, dst
         self.rows_of = [abi.rows_owned(height, block_rows, r, world) for r in range(world)]
         self.rows = len(self.rows_of[rank])
@@ -31,35 +42,61 @@ class FrameGather:
         self.stage = stage_through_host            # gloo rehearsal on a GPU box: collectives on host copies
         # [frames, rows, W, C]: a step's frames travel in ONE collective (few, large messages suit the
         # point-to-point xGMI links: 7 peers -> rank 0, each over its own link)
-        self.tile = torch.zeros((frames, self.max_rows, width, channels), dtype=dtype, device=device)
+        self.tiles = [torch.zeros((frames, self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(slots)]
+        self.tile = self.tiles[0]
+        self.work = [None] * slots
+        self._host = [None] * slots
         if rank == dst:
-            self.recv = [torch.empty_like(self.tile) for _ in range(world)] if world > 1 else None
+            self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(slots)] if world > 1 else None
             self.frame = torch.empty((frames, height, width, channels), dtype=dtype, device=device)
             self.index = [torch.as_tensor(np.asarray(r), dtype=torch.long, device=device) for r in self.rows_of]
         else:
             self.recv, self.frame, self.index = None, None, None
 
-    def gather(self):
-        """Gather every rank's `tile` to rank dst and de-interleave into `frame` [frames, H, W, C] (returned on
-        dst, else None)."""
+    def start(self, k=0):
+        """Begin the gather of slot k (asynchronous on the collective's stream)."""
         if self.world == 1:
-            return self.tile[:, : self.rows]
+            return
         if self.stage:
-            host = self.tile.cpu()
+            host = self.tiles[k].cpu()
             recv = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-            dist.gather(host, recv, dst=self.dst)
-            if self.rank == self.dst:
-                for r in range(self.world):
-                    self.recv[r].copy_(recv[r])
+            self.work[k] = dist.gather(host, recv, dst=self.dst, async_op=True)
+            self._host[k] = (host, recv)
         else:
-            dist.gather(self.tile, self.recv, dst=self.dst)
+            self.work[k] = dist.gather(self.tiles[k], self.recv[k] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+
+    def finish(self, k=0):
+        """Wait (stream-wise) for slot k's gather and de-interleave it into `frame` on rank dst.  Returns `frame`
+        [frames, H, W, C] on dst (None elsewhere, or if slot k has no gather in flight)."""
+        if self.world == 1:
+            return self.tiles[k][:, : self.rows]
+        if self.work[k] is None:
+            return None
+        self.work[k].wait()
+        self.work[k] = None
         if self.rank != self.dst:
             return None
+        if self.stage:
+            _, recv = self._host[k]
+            for r in range(self.world):
+                self.recv[k][r].copy_(recv[r])
         for r in range(self.world):
             n = len(self.rows_of[r])
             if n:
-                self.frame.index_copy_(1, self.index[r], self.recv[r][:, :n])
+                self.frame.index_copy_(1, self.index[r], self.recv[k][r][:, :n])
         return self.frame
+
+    def finish_all(self):
+        out = None
+        for k in range(len(self.tiles)):
+            f = self.finish(k)
+            out = f if f is not None else out
+        return out
+
+    def gather(self, k=0):
+        """Synchronous form: gather slot k and return the assembled frames on rank dst (None elsewhere)."""
+        self.start(k)
+        return self.finish(k)
 
 
 def split_params(width, height, lights, rank, world, block_rows, **kw):

@@ -37,9 +37,19 @@ def _worker(rank, world, port, block_rows, W, H, L, q):
         fg.tile[0, : fg.rows].copy_(torch.from_numpy(o["rgb8"]))
         fg.tile[1, : fg.rows].copy_(torch.from_numpy(255 - o["rgb8"]))
         frame = fg.gather()
-        hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32)
-        hg.tile[0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
-        hits = hg.gather()
+        # two slots, gathers in flight while the next slot is filled (the overlap scheme of bench.py)
+        hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32, slots=2)
+        hg.tiles[0][0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
+        hg.start(0)
+        hg.tiles[1][0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"] + 7))
+        hg.start(1)
+        hits = hg.finish(0)
+        if rank == 0:
+            hits = hits.clone()
+        shifted = hg.finish(1)
+        if rank == 0:
+            assert torch.equal(shifted, hits + 7)
+        assert hg.finish_all() is None
         if rank == 0:
             assert torch.equal(frame[1], 255 - frame[0])
             q.put((frame[0].numpy().copy(), hits[0].numpy()[..., 0].copy()))
