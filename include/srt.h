@@ -183,6 +183,7 @@ int srt_kat_ray_aabb(int device, uint32_t n, const float* ray_od, const float* b
 int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const float* tri_points, float* t);
 int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb);
 int srt_kat_interp_normal(int device, uint32_t n, const float* in12 /* 3 normals + barycentrics */, float* out3);   /* interpolateNormal :132-140 */
+int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* fast, float* lib);   /* the device powf: shipped form vs (float)pow(double) */
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q);
 
 const char* srt_strerror(int code);

@@ -616,6 +616,17 @@ int srt_kat_interp_normal(int device, uint32_t n, const float* in12, float* out3
     return o.down(out3, (size_t)n * 12);
 }
 
+int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* fast, float* lib) {
+    if (!n || !x || !y || !fast || !lib) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    DevBuf a, b, o, o2;
+    KAT_TRY(a.up(x, (size_t)n * 4)); KAT_TRY(b.up(y, (size_t)n * 4)); KAT_TRY(o.alloc((size_t)n * 4)); KAT_TRY(o2.alloc((size_t)n * 4));
+    hipLaunchKernelGGL(k_kat_pow, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, (const float*)b.p, (float*)o.p, (float*)o2.p);
+    HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    KAT_TRY(o.down(fast, (size_t)n * 4));
+    return o2.down(lib, (size_t)n * 4);
+}
+
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q) {
     if (!n || !lin || !tone || !q) return SRT_ERR_ARG;
     HIP_TRY(hipSetDevice(device));

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
 // a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
 // =================================================================================================
 template <bool COUNT, int NQCAP, bool FILTER>
-__global__ __launch_bounds__(256) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+__global__ __launch_bounds__(256, 6) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
     __shared__ uint32_t nq_all[4][NQCAP];
@@ -965,6 +965,13 @@ __global__ void k_kat_interp_normal(uint32_t n, const float* __restrict__ in12, 
     const V3 r = normalize3(mk((q[9] * q[0] + q[10] * q[3]) + q[11] * q[6], (q[9] * q[1] + q[10] * q[4]) + q[11] * q[7],
                                (q[9] * q[2] + q[10] * q[5]) + q[11] * q[8]));
     out3[i * 3] = r.x; out3[i * 3 + 1] = r.y; out3[i * 3 + 2] = r.z;
+}
+// pow_like_host against the f64 library pow on the same inputs: out[0] = fast path result, out[1] = (float)pow(double)
+__global__ void k_kat_pow(uint32_t n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ fast, float* __restrict__ lib) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = pow_like_host(x[i], y[i]);
+    lib[i] = (float)pow((double)x[i], (double)y[i]);
 }
 __global__ void k_kat_tonemap(uint32_t n, const float* __restrict__ lin, float reinhard, float gamma, float* __restrict__ tone, int32_t* __restrict__ q) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 # every symbol include/srt.h declares
 ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_scene_create", "srt_scene_destroy",
                "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
-               "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal")
+               "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -66,6 +66,7 @@ def load():
         L.srt_kat_ray_triangle.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _f32p]
         L.srt_kat_phong.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p]
         L.srt_kat_interp_normal.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p]
+        L.srt_kat_pow.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _f32p, _f32p]
         L.srt_kat_tonemap.argtypes = [C.c_int, C.c_uint32, _f32p, C.c_float, C.c_float, _f32p, _i32p]
         _lib = L
     return _lib
@@ -167,3 +168,10 @@ def kat_interp_normal(in12, device=0):
     L = load(); in12 = _f(in12); n = in12.shape[0]; out = np.empty((n, 3), np.float32)
     _check(L.srt_kat_interp_normal(device, n, in12.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p)), "srt_kat_interp_normal")
     return out
+
+
+def kat_pow(x, y, device=0):
+    """The device powf on vectors: (shipped form, (float)pow(double)(x, y))."""
+    L = load(); x, y = _f(x), _f(y); n = x.shape[0]; a = np.empty(n, np.float32); b = np.empty(n, np.float32)
+    _check(L.srt_kat_pow(device, n, x.ctypes.data_as(_f32p), y.ctypes.data_as(_f32p), a.ctypes.data_as(_f32p), b.ctypes.data_as(_f32p)), "srt_kat_pow")
+    return a, b

@@ -370,3 +370,21 @@ def test_many_objects_empty_objects_and_no_lights(srt, oracle):
     o0 = ds.render(p0); c0 = oracle.render(flat, p0)
     assert np.array_equal(o0["hit_id"], c0["hit_id"]) and np.array_equal(o0["rgb8"], c0["rgb8"])
     assert np.all(o0["rgb8"] == np.array(abi.REFERENCE_BACKGROUND, np.uint8)) and not o0["rgb_linear"].any()
+
+
+def test_device_pow_against_library_and_host(srt):
+    """The shipped powf (f64 fast path) returns the float the f64 library pow returns, and both are glibc's powf on all
+    but a sliver of inputs (glibc itself is not correctly rounded on ~0.08 %)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.powf.restype = ctypes.c_float; libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    rng = np.random.default_rng(1)
+    n = 300000
+    x = np.concatenate([rng.uniform(0, 1, n), rng.uniform(1e-6, 4, n // 2), [0.0, 1.0, 0.5, 1e-38, 1e-45, np.inf, -1.0, np.nan, 2.0]]).astype(np.float32)
+    y = np.concatenate([np.full(n // 2, 15.0), np.full(n // 2, 1.1), rng.choice([0.0, 0.5, 1, 2, 5, 32.5, 100], n // 2), [0.0, 3.0, 1.1, 1.1, 1.1, 1.1, 1.1, 1.1, 2000.0]]).astype(np.float32)
+    fast, libv = srt.kat_pow(x, y)
+    same = (bits(fast) == bits(libv)) | (np.isnan(fast) & np.isnan(libv))
+    assert (~same).mean() < 1e-5, f"{int((~same).sum())} fast-path results differ from the f64 library pow"
+    assert np.all(same[-9:]), "special values must take the library path"
+    sub = slice(0, 40000)
+    host = np.array([libm.powf(float(a), float(b)) for a, b in zip(x[sub], y[sub])], np.float32)
+    assert (bits(fast[sub]) != bits(host)).mean() < 3e-3 and np.abs(fast[sub] - host).max() < 1e-6
