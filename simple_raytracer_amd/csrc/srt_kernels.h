@@ -77,6 +77,7 @@ __device__ __forceinline__ bool tile_pixel(const DevParams& p, uint32_t& px, uin
 }
 // local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
 __device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
+    if (p.block_stride == 1) return p.block_first * p.block_rows + r;      // consecutive blocks (whole frame on one device): no division
     return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
 }
 // sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
@@ -290,7 +291,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                                                   unsigned long long* best, float2* dir,
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                  unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t) {
+                                                  unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d) {
     constexpr int P = 1 << (TWL + THL);           // rays per wavefront
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
@@ -433,7 +434,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     __builtin_amdgcn_wave_barrier();
 
     bool is_hit = false;
-    out_id = -1; out_t = __builtin_inff();
+    out_id = -1; out_t = __builtin_inff(); out_d = dmine;
     if (live) {
         const unsigned long long key = best[lane];
         int32_t id = -1;
@@ -470,9 +471,9 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ unsigned long long best_all[4][P];
     __shared__ float2 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
-    int32_t id; float t;
+    int32_t id; float t; V3 d;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t);
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d);
 }
 
 // =================================================================================================
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
 struct ShadowLds {
     float4 ray[2 * NQ_P];          // per ray slot: origin, direction
     float4 pixd[NQ_P];             // per hit rank: t, pixel lane, own object's node range
+    float2 pdir[NQ_P];             // per hit rank: primary ray direction x, y
     int2 selfr[NQ_P];              // per ray slot: node range of the hit object
     uint32_t flag[NQ_P];
 };
@@ -607,7 +609,7 @@ struct ShadowLds {
 // is the workgroup's 64-entry word array; ALL four waves of the workgroup must call this (it synchronises).
 template <bool SEQ, int NQCAP, bool FILTER>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
-                                             unsigned long long* bits, int32_t id, float t_hit,
+                                             unsigned long long* bits, int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4* ray = L.ray;
@@ -627,7 +629,9 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     const uint32_t nh = (uint32_t)__popc(hm);
     if (id >= 0) {
         const int2 self = s.obj_range[s.tri_obj[id]];
-        pixd[__popc(hm & ((1u << lane) - 1u))] = make_float4(t_hit, __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
+        const uint32_t rank = __popc(hm & ((1u << lane) - 1u));
+        pixd[rank] = make_float4(t_hit, __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
+        L.pdir[rank] = make_float2(d_hit.x, d_hit.y);
     }
     uint32_t nqn = 0, tqn = 0;
 
@@ -681,12 +685,13 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
             V3 so = mk(0.f, 0.f, 0.f), sd = mk(0.f, 0.f, 1.f);
             int2 self = make_int2(-1, -1);
             if (valid) {
-                const uint32_t hr = item / Lg;
+                const uint32_t hr = (Lg == 1u) ? item : item / Lg;
                 lg = item - hr * Lg;
                 const float4 pd = pixd[hr];
                 pl = __float_as_uint(pd.y);
                 self = make_int2(__float_as_int(pd.z), __float_as_int(pd.w));
-                const V3 d = primary_dir(p, tile_x + (pl & 3), image_row(p, tile_r + (pl >> 2)));
+                const float2 dxy = L.pdir[hr];
+                const V3 d = mk(dxy.x, dxy.y, p.focal);
                 const uint32_t l = l0 + lg;
                 const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
                 so = d * pd.x;                                    // :326
@@ -806,8 +811,9 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
-    if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; }
-    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, shadow_bits, counters);
+    V3 d = mk(0.f, 0.f, p.focal);
+    if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
+    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters);
 }
 
 // =================================================================================================
@@ -826,11 +832,11 @@ __global__ __launch_bounds__(256, 6) void k_trace_nq(DevScene s, DevParams p, in
     __shared__ ShadowLds lds_all[4];
     __shared__ unsigned long long bits[64];
     const uint32_t wave = threadIdx.x >> 6;
-    int32_t id; float t;
+    int32_t id; float t; V3 d;
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t);
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d);
     __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, shadow_bits, counters);
+    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters);
 }
 
 // =================================================================================================
