@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 logic on a box with fewer "
                          "GPUs than ranks (ranks share devices, tiles are staged through host memory)")
+    ap.add_argument("--emulate-split", default="", help="R/N: time rank R's share of an N-way scanline split on ONE GPU (no collective); "
+                                                         "diagnostic for the strong-scaling ceiling, not a bench line")
     ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
     args = ap.parse_args()
 
@@ -87,7 +89,9 @@ def main():
     scene = lib.DeviceScene(g.flat, device=local_rank)
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
-    p = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS, flags=args.variant << 8)
+    emu = [int(x) for x in args.emulate_split.split("/")] if args.emulate_split else None
+    split_rank, split_world = (emu if emu else (rank, world))
+    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8)
     rows = scene.rows(p)
     dev = torch.device("cuda", local_rank)
     hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
@@ -98,6 +102,10 @@ def main():
     SLOTS = 2 if world > 1 else 1        # double-buffered tiles: the gather of step s overlaps the rendering of step s+1
     gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B,
                                 stage_through_host=(args.backend == "gloo"), slots=SLOTS)
+    if emu:
+        assert world == 1
+        gather.tiles = [torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev)]
+        gather.tile = gather.tiles[0]
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
@@ -110,7 +118,7 @@ def main():
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
     graphs = None
     if not args.no_graph and B % 2 == 0:
-        p_quiet = tiling.split_params(W, H, lights, rank, world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING)
+        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING)
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
             graphs = []

@@ -95,5 +95,19 @@ def build_all(force=False, verbose=False):
     return [build_hip(force, verbose), build_host(force, verbose), build_examples(force, verbose)]
 
 
+def build_diag(verbose=False):
+    """Diagnostic build with in-kernel cycle stamps (-DSRT_DIAG): libsrt_hip_diag.so, never loaded by the product."""
+    out = os.path.join(HERE, "libsrt_hip_diag.so")
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-DSRT_DIAG", "-o", out, os.path.join(CSRC, "srt_hip.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed for the diagnostic build")
+    return out
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
+    if "--diag" in sys.argv:
+        print(build_diag(verbose=True))
+    else:
+        build_all(force="--force" in sys.argv, verbose=True)

@@ -282,8 +282,17 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
 // pre-order walk (skip links) instead -- any tree shape is handled with bounded LDS.
 // =================================================================================================
 constexpr int NQ_P = 16;                    // rays per wavefront of the shadow kernel (4x4 pixel quadrant)
+constexpr int LQ_WORDS = 2 * (64 + 64);     // (leaf, ray) pair queue of the node-queue kernels: < 64 left over + <= 64 per push, 2 words each
 
 // TWL / THL: log2 of the tile width / height a wavefront owns (shipped: 4x4); FILTER: filtered slab predicate.
+#ifdef SRT_DIAG
+// Diagnostic build only (python -m simple_raytracer_amd.build --diag -> libsrt_hip_diag.so, never shipped): per-wave
+// cycle stamps of the closest-hit phase, written where rgb_linear would go (8 x u64 per wave).
+#define SRT_STAMP(v) do { v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+#else
+#define SRT_STAMP(v) do { } while (0)
+#endif
+
 // The phase runs per wavefront on LDS the caller provides: nq[NQCAP], tq[QCAP], best[P], dir[P].  On return the
 // lanes < P hold their pixel's hit id and t (also written to hit_id / t_out, with the final pixel for misses).
 template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
@@ -310,43 +319,62 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     unsigned long long n_node = 0, n_tri = 0;
     uint32_t nqn = 0, tqn = 0;                       // wave-uniform queue lengths
     __builtin_amdgcn_wave_barrier();
+    unsigned long long dg_t0 = 0, dg_a = 0, dg_b = 0, dg_test = 0, dg_commit = 0, dg_tri = 0, dg_steps = 0, dg_batches = 0, dg_items = 0, dg_titems = 0;
+    (void)dg_t0; (void)dg_a; (void)dg_b; (void)dg_test; (void)dg_commit; (void)dg_tri; (void)dg_steps; (void)dg_batches; (void)dg_items; (void)dg_titems;
+    SRT_STAMP(dg_t0);
 
-    // one batch of <= 64 queued (triangle, pixel) pairs, one per lane
+    // One batch of <= 64 queued (leaf, pixel) pairs, one per lane: the lane runs Moller-Trumbore over the leaf's
+    // triangles in stored order (next triangle's loads issued before the current test), keeps the first minimum
+    // (strict '<', :429) and merges once with the LDS atomicMin.  A queue entry is two words: the leaf's
+    // (first << 5 | count) and the pixel lane.
     auto tri_batch = [&]() {
         const uint32_t m = tqn < 64 ? tqn : 64;
         tqn -= m;
+#ifdef SRT_DIAG
+        unsigned long long c0, c1; SRT_STAMP(c0); dg_batches++; dg_titems += m;
+#endif
         if (lane < m) {
-            const uint32_t e = tq[tqn + lane];
-            const uint32_t pl = e & 63u, tri = e >> 6;
+            const uint32_t info = tq[2 * (tqn + lane)], pl = tq[2 * (tqn + lane) + 1];
+            const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
             const float2 dxy = dir[pl];
-            const size_t ti = (size_t)tri * 3;
-            const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-            const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-            if (COUNT) n_tri++;
-            const float t = ray_triangle(o, mk(dxy.x, dxy.y, p.focal), mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
-            // candidate iff t != -inf && t < +inf (the initial distanceComparison, :408); NaN fails '<'
-            if (t != SRT_NEG_INF && t < __builtin_inff()) {
-                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);     // -0.0 ties with +0.0
-                atomicMin(&best[pl], ((unsigned long long)tb << 32) | tri);
+            const V3 d = mk(dxy.x, dxy.y, p.focal);
+            float bt = __builtin_inff();
+            uint32_t bi = 0;
+            // two triangles per iteration: their Moller-Trumbore chains are independent and interleave (the chain of a
+            // single test is ~100 dependent VALU ops); the update order keeps the first minimum
+            const float4* tp = tris4 + (size_t)first * 3;
+            for (uint32_t k = 0; k < cnt; k += 2) {
+                const bool two = k + 1 < cnt;
+                const float4 a0 = tp[0], a1 = tp[1]; const float az = reinterpret_cast<const float*>(tp + 2)[0];
+                const float4* tq_ = two ? tp + 3 : tp;
+                const float4 b0 = tq_[0], b1 = tq_[1]; const float bz = reinterpret_cast<const float*>(tq_ + 2)[0];
+                tp += 6;
+                if (COUNT) n_tri += two ? 2 : 1;
+                const float ta = ray_triangle(o, d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, az));
+                const float tb_ = ray_triangle(o, d, mk(b0.x, b0.y, b0.z), mk(b0.w, b1.x, b1.y), mk(b1.z, b1.w, bz));
+                // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
+                if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
+                if (two && tb_ != SRT_NEG_INF && tb_ < bt) { bt = tb_; bi = first + k + 1; }
+            }
+            if (bt < __builtin_inff()) {
+                const uint32_t tb = (bt == 0.0f) ? 0u : __float_as_uint(bt);     // -0.0 ties with +0.0
+                atomicMin(&best[pl], ((unsigned long long)tb << 32) | bi);
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+        SRT_STAMP(c1); dg_tri += c1 - c0;
+#endif
     };
-    // queue the triangles [first, first+cnt) of each lane's passing leaf (cnt = 0: nothing), <= 8 per lane per round
-    auto push_tris = [&](uint32_t first, uint32_t cnt, uint32_t pl) {
-        uint32_t off = 0;
-        while (__ballot(off < cnt)) {
-            const uint32_t c = off < cnt ? ((cnt - off) < (uint32_t)PUSH_MAX ? (cnt - off) : (uint32_t)PUSH_MAX) : 0u;
-            uint32_t pre = 0, tot = 0;
-            #pragma unroll
-            for (int bit = 0; bit < 4; bit++) {
-                const unsigned long long m = __ballot((c >> bit) & 1u);
-                pre += lane_prefix(m) << bit;
-                tot += (uint32_t)__popcll(m) << bit;
+    // queue each lane's passing leaf (is_leaf = false: nothing)
+    auto push_tris = [&](uint32_t info, bool is_leaf, uint32_t pl) {
+        const unsigned long long lm = __ballot(is_leaf);
+        if (lm) {
+            if (is_leaf) {
+                const uint32_t pos = tqn + lane_prefix(lm);
+                tq[2 * pos] = info; tq[2 * pos + 1] = pl;
             }
-            for (uint32_t k = 0; k < c; k++) tq[tqn + pre + k] = ((first + off + k) << 6) | pl;
-            tqn += tot;
-            off += PUSH_MAX;
+            tqn += (uint32_t)__popcll(lm);
             __builtin_amdgcn_wave_barrier();
             while (tqn >= 64) tri_batch();
         }
@@ -370,10 +398,14 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         while (nqn) {
             const uint32_t m = nqn < 64 ? nqn : 64;
             nqn -= m;
+#ifdef SRT_DIAG
+            SRT_STAMP(dg_a); dg_steps++; dg_items += m;
+            const unsigned long long tri_before = dg_tri;
+#endif
             const bool have = lane < m;
-            uint32_t pl = 0, cnt = 0, first = 0;
+            uint32_t pl = 0;
             int32_t node = 0, info = -1, skip = 0;
-            bool inner = false;
+            bool inner = false, leafp = false;
             V3 d = mk(0.f, 0.f, p.focal);
             if (have) {
                 const uint32_t e = nq[nqn + lane];
@@ -393,10 +425,13 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                 }
                 if (pass) {
                     if (info < 0) inner = true;
-                    else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
+                    else leafp = (info & LEAF_MAX) != 0;
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+            SRT_STAMP(dg_b); dg_test += dg_b - dg_a;
+#endif
             const unsigned long long im = __ballot(inner);
             const uint32_t n_in = (uint32_t)__popcll(im);
             if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
@@ -406,32 +441,49 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                     nq[pos + 1] = ((uint32_t)(node + 1) << 6) | pl;   // left child on top: popped first
                 }
                 nqn += 2 * n_in;
-                push_tris(first, cnt, pl);
+                push_tris((uint32_t)info, leafp, pl);
             } else {
                 // queue full: finish these subtrees with the stackless pre-order walk (i = pass ? i+1 : skip[i])
-                push_tris(first, cnt, pl);
+                push_tris((uint32_t)info, leafp, pl);
                 int32_t i = inner ? node + 1 : 0, end = inner ? skip : 0;
                 while (__ballot(i < end)) {
-                    uint32_t c2 = 0, f2 = 0;
+                    int32_t inf2 = -1;
+                    bool lp2 = false;
                     if (i < end) {
                         const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
-                        const int32_t sk = __float_as_int(b.z), inf2 = __float_as_int(b.w);
+                        const int32_t sk = __float_as_int(b.z);
+                        inf2 = __float_as_int(b.w);
                         if (COUNT) n_node++;
                         if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
-                            if (inf2 >= 0) { c2 = (uint32_t)(inf2 & LEAF_MAX); f2 = (uint32_t)(inf2 >> LEAF_SHIFT); }
+                            lp2 = inf2 >= 0 && (inf2 & LEAF_MAX) != 0;
                             i = i + 1;
                         } else {
                             i = sk;
                         }
                     }
-                    push_tris(f2, c2, pl);
+                    push_tris((uint32_t)inf2, lp2, pl);
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+            { unsigned long long c2_; SRT_STAMP(c2_); dg_commit += (c2_ - dg_b) - (dg_tri - tri_before); }
+#endif
         }
     }
     while (tqn) tri_batch();
     __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+    {
+        unsigned long long c3; SRT_STAMP(c3);
+        if (lane == 0 && rgb_linear) {
+            unsigned long long* dgp = reinterpret_cast<unsigned long long*>(rgb_linear) +
+                                      (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            dgp[0] = c3 - dg_t0; dgp[1] = dg_steps; dgp[2] = dg_batches; dgp[3] = dg_test; dgp[4] = dg_commit; dgp[5] = dg_tri;
+            dgp[6] = dg_items; dgp[7] = dg_titems;
+        }
+        rgb_linear = nullptr;
+    }
+#endif
 
     bool is_hit = false;
     out_id = -1; out_t = __builtin_inff(); out_d = dmine;
@@ -467,7 +519,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
                                                         uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
     constexpr int P = 1 << (TWL + THL);
     __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][P];
     __shared__ float2 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
@@ -635,37 +687,39 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     }
     uint32_t nqn = 0, tqn = 0;
 
+    // one batch of <= 64 queued (leaf, ray) pairs: the lane walks the leaf's triangles until one hits
     auto tri_batch = [&]() {
         const uint32_t m = tqn < 64 ? tqn : 64;
         tqn -= m;
         if (lane < m) {
-            const uint32_t e = tq[tqn + lane];
-            const uint32_t rs = e & 63u, tri = e >> 6;
+            const uint32_t info = tq[2 * (tqn + lane)], rs = tq[2 * (tqn + lane) + 1];
             if (!flag[rs]) {
-                const float4 ro = ray[rs], rd = ray[NQ_P + rs];
-                const size_t ti = (size_t)tri * 3;
-                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-                const float t = ray_triangle(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
-                if (t != SRT_NEG_INF) flag[rs] = 1u;             // any t >= 0, NaN included (:335)
+                const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
+                const float4 ro4 = ray[rs], rd4 = ray[NQ_P + rs];
+                const V3 ro = mk(ro4.x, ro4.y, ro4.z), rd = mk(rd4.x, rd4.y, rd4.z);
+                const float4* tp = tris4 + (size_t)first * 3;
+                float4 t0 = tp[0], t1 = tp[1];
+                float e2z = reinterpret_cast<const float*>(tp + 2)[0];
+                bool hit = false;
+                for (uint32_t k = 0; k < cnt && !hit; k++) {
+                    const float4 c0_ = t0, c1_ = t1; const float cz = e2z;
+                    if (k + 1 < cnt) { tp += 3; t0 = tp[0]; t1 = tp[1]; e2z = reinterpret_cast<const float*>(tp + 2)[0]; }
+                    const float t = ray_triangle(ro, rd, mk(c0_.x, c0_.y, c0_.z), mk(c0_.w, c1_.x, c1_.y), mk(c1_.z, c1_.w, cz));
+                    hit = t != SRT_NEG_INF;                          // any t >= 0, NaN included (:335)
+                }
+                if (hit) flag[rs] = 1u;
             }
         }
         __builtin_amdgcn_wave_barrier();
     };
-    auto push_tris = [&](uint32_t first, uint32_t cnt, uint32_t rs) {
-        uint32_t off = 0;
-        while (__ballot(off < cnt)) {
-            const uint32_t c = off < cnt ? ((cnt - off) < (uint32_t)PUSH_MAX ? (cnt - off) : (uint32_t)PUSH_MAX) : 0u;
-            uint32_t pre = 0, tot = 0;
-            #pragma unroll
-            for (int bit = 0; bit < 4; bit++) {
-                const unsigned long long m = __ballot((c >> bit) & 1u);
-                pre += lane_prefix(m) << bit;
-                tot += (uint32_t)__popcll(m) << bit;
+    auto push_tris = [&](uint32_t info, bool is_leaf, uint32_t rs) {
+        const unsigned long long lm = __ballot(is_leaf);
+        if (lm) {
+            if (is_leaf) {
+                const uint32_t pos = tqn + lane_prefix(lm);
+                tq[2 * pos] = info; tq[2 * pos + 1] = rs;
             }
-            for (uint32_t k = 0; k < c; k++) tq[tqn + pre + k] = ((first + off + k) << 6) | rs;
-            tqn += tot;
-            off += PUSH_MAX;
+            tqn += (uint32_t)__popcll(lm);
             __builtin_amdgcn_wave_barrier();
             while (tqn >= 64) tri_batch();
         }
@@ -725,9 +779,9 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                     while (nqn) {
                         const uint32_t m = nqn < 64 ? nqn : 64;
                         nqn -= m;
-                        uint32_t rs = 0, cnt = 0, first = 0;
+                        uint32_t rs = 0;
                         int32_t node = 0, info = -1, skip = 0;
-                        bool inner = false;
+                        bool inner = false, leafp = false;
                         V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
                         if (lane < m) {
                             const uint32_t e = nq[nqn + lane];
@@ -747,7 +801,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                                 }
                                 if (pass) {
                                     if (info < 0) inner = true;
-                                    else { cnt = (uint32_t)(info & LEAF_MAX); first = (uint32_t)(info >> LEAF_SHIFT); }
+                                    else leafp = (info & LEAF_MAX) != 0;
                                 }
                             }
                         }
@@ -761,26 +815,28 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                                 nq[pos + 1] = ((uint32_t)(node + 1) << 6) | rs;
                             }
                             nqn += 2 * n_in;
-                            push_tris(first, cnt, rs);
+                            push_tris((uint32_t)info, leafp, rs);
                         } else {
-                            push_tris(first, cnt, rs);
+                            push_tris((uint32_t)info, leafp, rs);
                             int32_t i = inner ? node + 1 : 0, end = inner ? skip : 0;
                             while (__ballot(i < end)) {
-                                uint32_t c2 = 0, f2 = 0;
+                                int32_t inf2 = -1;
+                                bool lp2 = false;
                                 if (i < end) {
                                     if (flag[rs]) { i = end; }
                                     else {
                                         const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
-                                        const int32_t sk = __float_as_int(b.z), inf2 = __float_as_int(b.w);
+                                        const int32_t sk = __float_as_int(b.z);
+                                        inf2 = __float_as_int(b.w);
                                         if (ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y)) {
-                                            if (inf2 >= 0) { c2 = (uint32_t)(inf2 & LEAF_MAX); f2 = (uint32_t)(inf2 >> LEAF_SHIFT); }
+                                            lp2 = inf2 >= 0 && (inf2 & LEAF_MAX) != 0;
                                             i = i + 1;
                                         } else {
                                             i = sk;
                                         }
                                     }
                                 }
-                                push_tris(f2, c2, rs);
+                                push_tris((uint32_t)inf2, lp2, rs);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -805,7 +861,7 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
                                                    const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
                                                    unsigned long long* __restrict__ counters) {
     __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ ShadowLds lds_all[4];
     __shared__ unsigned long long bits[64];          // per light of the current group: shadowed pixels of the 8x8 tile
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -826,7 +882,7 @@ __global__ __launch_bounds__(256, 6) void k_trace_nq(DevScene s, DevParams p, in
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
     __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][QCAP];
+    __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][NQ_P];
     __shared__ float2 dir_all[4][NQ_P];
     __shared__ ShadowLds lds_all[4];
