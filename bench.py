@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the frames of a step are spread over (each with its own scene handle and buffers).  Default: 1 "
+                         "at N = 1 (kernels run alone, so their durations are the ones rocprofv3 reports), 4 at N > 1, where a rank's "
+                         "share of a frame is too small to fill the chip and independent frames overlap their ramp-up and tails")
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 logic on a box with fewer "
@@ -86,7 +90,9 @@ def main():
         g = soup_workload(args.tris)
     else:
         g = gu.GoldenScene(args.workload)
-    scene = lib.DeviceScene(g.flat, device=local_rank)
+    S = max(1, min(args.streams if args.streams > 0 else (1 if (world == 1 and not args.emulate_split) else 4), B))
+    scenes_ = [lib.DeviceScene(g.flat, device=local_rank) for _ in range(S)]     # one handle (workspace, counters) per stream
+    scene = scenes_[0]
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
     emu = [int(x) for x in args.emulate_split.split("/")] if args.emulate_split else None
@@ -94,9 +100,10 @@ def main():
     p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8)
     rows = scene.rows(p)
     dev = torch.device("cuda", local_rank)
-    hit = torch.empty((rows, W), dtype=torch.int32, device=dev)
-    tbuf = torch.empty((rows, W), dtype=torch.float32, device=dev)
-    lin = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
+    hit = torch.empty((S, rows, W), dtype=torch.int32, device=dev)
+    tbuf = torch.empty((S, rows, W), dtype=torch.float32, device=dev)
+    lin = torch.empty((S, rows, W, 3), dtype=torch.float32, device=dev)
+    side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
     SLOTS = 2 if world > 1 else 1        # double-buffered tiles: the gather of step s overlaps the rendering of step s+1
@@ -109,10 +116,20 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
-    def render_frames(pp, slot=0):
+    def render_frames(pp, slot=0, streams=True):
+        """The B frames of a step.  With S > 1 frame f goes to stream f % S (fork from / join into the current stream,
+        which is what a capturing graph records as parallel branches)."""
+        cur = torch.cuda.current_stream()
+        use = side if (streams and S > 1) else []
+        for st in use:
+            st.wait_stream(cur)
         for f in range(B):
-            scene.render_device(pp, stream=torch.cuda.current_stream().cuda_stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(),
-                                rgb_linear=lin.data_ptr(), rgb8=gather.tiles[slot].data_ptr() + f * frame_bytes)
+            k = f % S if use else 0
+            st = use[k] if use else cur
+            scenes_[k].render_device(pp, stream=st.cuda_stream, hit_id=hit[k].data_ptr(), t=tbuf[k].data_ptr(),
+                                     rgb_linear=lin[k].data_ptr(), rgb8=gather.tiles[slot].data_ptr() + f * frame_bytes)
+        for st in use:
+            cur.wait_stream(st)
 
     # The B renders of a step are launch-bound when a rank owns 1/8 of a frame: capture them once into a hipGraph
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
@@ -166,8 +183,9 @@ def main():
         dt = float(tt.item())
     # per-kernel durations: HIP events on the launch stream over B eager renders of the same frames (the events of
     # a captured graph cannot be read back), averaged by srt_sync
-    scene.sync()
-    render_frames(p)
+    for sc_ in scenes_:
+        sc_.sync()
+    render_frames(p, streams=False)
     torch.cuda.synchronize()
     st = scene.sync()
     rgb8 = gather.tiles[0][0]
@@ -175,7 +193,7 @@ def main():
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
                          flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8))
-    scene.render_device(pc, stream=stream, hit_id=hit.data_ptr(), t=tbuf.data_ptr(), rgb_linear=lin.data_ptr(), rgb8=rgb8.data_ptr())
+    scene.render_device(pc, stream=stream, hit_id=hit[0].data_ptr(), t=tbuf[0].data_ptr(), rgb_linear=lin[0].data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
     rays_rank = sc["primary_rays"] + sc["shadow_rays"]
@@ -224,7 +242,7 @@ def main():
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
                        "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step, overlapped with the next step's rendering",
-                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5), "launch": "hipGraph replay" if graph is not None else "eager",
+                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + f", {S} stream(s)",
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,

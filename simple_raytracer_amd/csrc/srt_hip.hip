@@ -351,6 +351,8 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     unsigned long long* ctr_next = s->d_counters + ((s->render_seq + 1) & 1) * NCTR;
     s->render_seq++;
     s->d_ctr_last = ctr;
+    // a counting run must not inherit whatever replayed graphs left in the set (their frames use fixed sets)
+    if (p->flags & SRT_FLAG_COUNT_WORK) HIP_TRY(hipMemsetAsync(ctr, 0, NCTR * sizeof(unsigned long long), stream));
 
     if ((p->flags & SRT_FLAG_SMOOTH_NORMALS) && (!s->dev.tri_normals || variant_of(p) == 1)) return SRT_ERR_ARG;   // needs vertex normals
     DevParams dp;
