@@ -414,16 +414,12 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         const bool fused = (variant == 0 || variant > 10) && p->n_lights;
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
-            if (count) hipLaunchKernelGGL((k_closest_hit_q<true, false>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
-            else       hipLaunchKernelGGL((k_closest_hit_q<false, false>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
+            if (count) hipLaunchKernelGGL((k_closest_hit_q<true>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
+            else       hipLaunchKernelGGL((k_closest_hit_q<false>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
             break;
         case 3: LAUNCH_NQ(160, 2, 2, false); break;      // tiny node queue: exercises the stackless overflow path
         case 4: LAUNCH_NQ(512, 2, 2, false); break;      // shipped geometry with exact divides only
-        case 5: LAUNCH_NQ(1024, 3, 2, false); break;     // 8x4 pixels per wave
-        case 6: LAUNCH_NQ(1024, 2, 1, false); break;     // 4x2
-        case 7: LAUNCH_NQ(1024, 2, 2, false); break;     // larger node queue
-        case 8: LAUNCH_NQ(2048, 3, 3, false); break;     // 8x8
-        case 9: LAUNCH_NQ(512, 2, 1, true); break;
+        case 5: LAUNCH_NQ(1024, 3, 2, false); break;     // 8x4 pixels per wave, 1024-entry queue (tile-size experiment)
         case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
         default:                                           // shipped: closest hit + shadow rays fused in one launch
             if (fused) {
@@ -441,7 +437,6 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
             if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (variant == 7) hipLaunchKernelGGL((k_shadow_nq<false, 1024, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         }

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-template <bool COUNT, bool PREFETCH>
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                        float* __restrict__ t_out, float* __restrict__ rgb_linear,
                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
@@ -181,11 +181,6 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
             if (active) {
                 const float4 a = na, b = nb;
                 const int32_t skip = __float_as_int(b.z), leaf = __float_as_int(b.w);
-                float4 pa, pb;
-                if (PREFETCH) {                          // node i+1 is the successor whenever the test passes
-                    const int32_t j = (i + 1 < n) ? i + 1 : i;
-                    pa = nodes4[2 * (size_t)j]; pb = nodes4[2 * (size_t)j + 1];
-                }
                 if (COUNT && leaf_off == 0) n_node++;
                 int32_t next;
                 bool stay = false;
@@ -201,8 +196,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
                     next = skip;
                 }
                 if (!stay) {
-                    if (PREFETCH && next == i + 1) { na = pa; nb = pb; }
-                    else if (next < n) { na = nodes4[2 * (size_t)next]; nb = nodes4[2 * (size_t)next + 1]; }
+                    if (next < n) { na = nodes4[2 * (size_t)next]; nb = nodes4[2 * (size_t)next + 1]; }
                     i = next;
                 }
             }

@@ -190,7 +190,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 10])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -228,7 +228,7 @@ def test_big_leaves_and_signed_zero_t(srt, oracle):
                          obj_root=[0], tri_points=pts, tri_obj=np.zeros(n, np.int32),
                          obj_color=[[0.8, 0.6, 0.2]], obj_material=[[0.2, 0.5, 15.0]])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 1, 2, 3, 5, 6, 7, 8, 10):
+    for variant in (0, 1, 2, 3, 4, 5, 10):
         p = abi.make_params(96, 64, [[100.0, -200.0, 50.0]], flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
