@@ -16,7 +16,8 @@ for _ in range(2):
     o = ds.render(p)
 n_waves = ((W + 7) // 8) * ((H + 7) // 8) * 4
 d = o["rgb_linear"].reshape(-1).view(np.uint64)[: n_waves * 8].reshape(n_waves, 8).astype(np.float64)
-tot, steps, batches, test, commit, tri, items, titems = d.T
+tot, steps, batches, test, commit, tri, pop, load = d.T
+items = titems = np.zeros_like(tot)
 print(f"waves {n_waves}; kernel {o['stats']['ms_primary']*1e3:.1f} us (stamped build)")
 order = np.argsort(-tot)
 def row(sel, name):
@@ -30,4 +31,7 @@ light = np.where(steps <= 1)[0]
 row(light, "<=1 step")
 print("per node step (top 1000):  test %.0f cyc, commit+push %.0f cyc;  per tri batch %.0f cyc" % (
     test[order[:1000]].sum() / steps[order[:1000]].sum(), commit[order[:1000]].sum() / steps[order[:1000]].sum(), tri[order[:1000]].sum() / batches[order[:1000]].sum()))
+top = order[:1000]
+print("per node step (top 1000): LDS pop %.0f cyc, node loads %.0f cyc, slab test (rest of 'test') %.0f cyc" % (
+    pop[top].sum() / steps[top].sum(), load[top].sum() / steps[top].sum(), test[top].sum() / steps[top].sum()))
 print("sum of wave cycles / 1e6: %.1f" % (tot.sum() / 1e6))

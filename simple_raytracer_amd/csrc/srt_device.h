@@ -109,14 +109,14 @@ __device__ __forceinline__ bool ray_aabb_filtered(V3 o, RayRcp rc, float mnx, fl
     float minX = __builtin_fminf(x0, x1), maxX = __builtin_fmaxf(x0, x1);
     const float minY = __builtin_fminf(y0, y1), maxY = __builtin_fmaxf(y0, y1);
     const float minZ = __builtin_fminf(z0, z1), maxZ = __builtin_fmaxf(z0, z1);
-    // magnitude of everything involved: non-finite anywhere -> ambiguous (0 * inf, x / 0, overflow)
-    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0) + __builtin_fabsf(x1), __builtin_fabsf(y0) + __builtin_fabsf(y1)),
-                                      __builtin_fabsf(z0) + __builtin_fabsf(z1));
-    bool amb = !(big < 1.0e30f) | !(x0 == x0) | !(x1 == x1) | !(y0 == y0) | !(y1 == y1) | !(z0 == z0) | !(z1 == z1);
+    // anything non-finite (0 * inf, x / 0, overflow) or absurdly large makes the sum NaN / inf / huge -> ambiguous
+    const float big = ((__builtin_fabsf(x0) + __builtin_fabsf(x1)) + (__builtin_fabsf(y0) + __builtin_fabsf(y1))) +
+                      (__builtin_fabsf(z0) + __builtin_fabsf(z1));
+    bool amb = !(big < 1.0e30f);
     // decide (a < b): certain when |a - b| exceeds the margin
     #define SRT_LT(a, b, res)                                                            \
         {                                                                                \
-            const float m_ = E * (__builtin_fabsf(a) + __builtin_fabsf(b)) + TINY;      \
+            const float m_ = __builtin_fmaf(E, __builtin_fabsf(a) + __builtin_fabsf(b), TINY);   \
             const float df_ = (b) - (a);                                                 \
             res = df_ > 0.0f;                                                            \
             amb |= !(__builtin_fabsf(df_) > m_);                                         \

@@ -291,7 +291,7 @@ constexpr int LQ_WORDS = 2 * (64 + 64);     // (leaf, ray) pair queue of the nod
 // lanes < P hold their pixel's hit id and t (also written to hit_id / t_out, with the final pixel for misses).
 template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
 __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq,
-                                                  unsigned long long* best, float2* dir,
+                                                  unsigned long long* best, float4* dir,
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d) {
@@ -307,12 +307,14 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     if (lane < P) {
         best[lane] = ~0ull;
         if (live) dmine = primary_dir(p, px, image_row(p, r));
-        dir[lane] = make_float2(dmine.x, dmine.y);
+        dir[lane] = make_float4(dmine.x, dmine.y, __builtin_amdgcn_rcpf(dmine.x), __builtin_amdgcn_rcpf(dmine.y));   // + reciprocals for the filtered slab test
     }
+    const float rcp_focal = __builtin_amdgcn_rcpf(p.focal);
     const unsigned long long livem = __ballot(live);
     unsigned long long n_node = 0, n_tri = 0;
     uint32_t nqn = 0, tqn = 0;                       // wave-uniform queue lengths
     __builtin_amdgcn_wave_barrier();
+    unsigned long long dg_pop = 0, dg_load = 0; (void)dg_pop; (void)dg_load;
     unsigned long long dg_t0 = 0, dg_a = 0, dg_b = 0, dg_test = 0, dg_commit = 0, dg_tri = 0, dg_steps = 0, dg_batches = 0, dg_items = 0, dg_titems = 0;
     (void)dg_t0; (void)dg_a; (void)dg_b; (void)dg_test; (void)dg_commit; (void)dg_tri; (void)dg_steps; (void)dg_batches; (void)dg_items; (void)dg_titems;
     SRT_STAMP(dg_t0);
@@ -330,7 +332,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         if (lane < m) {
             const uint32_t info = tq[2 * (tqn + lane)], pl = tq[2 * (tqn + lane) + 1];
             const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
-            const float2 dxy = dir[pl];
+            const float4 dxy = dir[pl];
             const V3 d = mk(dxy.x, dxy.y, p.focal);
             float bt = __builtin_inff();
             uint32_t bi = 0;
@@ -404,15 +406,22 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             if (have) {
                 const uint32_t e = nq[nqn + lane];
                 pl = e & 63u; node = (int32_t)(e >> 6);
+#ifdef SRT_DIAG
+                { unsigned long long c_; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SRT_STAMP(c_); dg_pop += c_ - dg_a; dg_a = c_; }
+#endif
                 const float4 a = nodes4[2 * (size_t)node], b = nodes4[2 * (size_t)node + 1];
-                const float2 dxy = dir[pl];
+                const float4 dxy = dir[pl];
+#ifdef SRT_DIAG
+                { unsigned long long c_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SRT_STAMP(c_); dg_load += c_ - dg_a; dg_a = c_; }
+#endif
                 d = mk(dxy.x, dxy.y, p.focal);
                 skip = __float_as_int(b.z); info = __float_as_int(b.w);
                 if (COUNT) n_node++;
                 bool pass;
                 if (FILTER) {
                     bool amb;
-                    pass = ray_aabb_filtered(o, ray_rcp(d), a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                    RayRcp rc; rc.x = dxy.z; rc.y = dxy.w; rc.z = rcp_focal;
+                    pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
                     if (amb) pass = ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y);      // rare: exact divides decide
                 } else {
                     pass = ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y);
@@ -473,7 +482,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             unsigned long long* dgp = reinterpret_cast<unsigned long long*>(rgb_linear) +
                                       (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
             dgp[0] = c3 - dg_t0; dgp[1] = dg_steps; dgp[2] = dg_batches; dgp[3] = dg_test; dgp[4] = dg_commit; dgp[5] = dg_tri;
-            dgp[6] = dg_items; dgp[7] = dg_titems;
+            dgp[6] = dg_pop; dgp[7] = dg_load;
         }
         rgb_linear = nullptr;
     }
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][P];
-    __shared__ float2 dir_all[4][P];
+    __shared__ float4 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
@@ -871,14 +880,14 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
 // tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
 // a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
 // =================================================================================================
-template <bool COUNT, int NQCAP, bool FILTER>
-__global__ __launch_bounds__(256, 6) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+template <bool COUNT, int NQCAP, bool FILTER, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][NQ_P];
-    __shared__ float2 dir_all[4][NQ_P];
+    __shared__ float4 dir_all[4][NQ_P];
     __shared__ ShadowLds lds_all[4];
     __shared__ unsigned long long bits[64];
     const uint32_t wave = threadIdx.x >> 6;
