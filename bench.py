@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=36, help="frames rendered per step (the reference renders a 36-frame orbit per run)")
-    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground", "soup"])
+    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground", "main_nocats", "soup"])
     ap.add_argument("--tris", type=int, default=1000000, help="triangle count of the synthetic soup workload (BASELINE.json configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -237,6 +237,8 @@ def main():
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
                        else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
+                             else f"main_nocats: the scene of the reference's main() (ground cube, bunny, 3 textured trees; the cats are a missing blob), "
+                                  f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[3] shape]" if args.workload == "main_nocats"
                              else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s) [BASELINE.json configs[4], spp 1]"),
                        "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",

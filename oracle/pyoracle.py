@@ -215,6 +215,13 @@ class RefScene:
         pts = np.ascontiguousarray(points, np.float32).reshape(-1, 12)
         self.L.ref_om_add_object(self.om, name.encode(), C.c_uint32(pts.shape[0]), _p(pts, _f32p))
 
+    def add_textured_object(self, name, points, texcoord, texname, texture):
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 12)
+        tc = np.ascontiguousarray(texcoord, np.float32).reshape(-1, 6)
+        tex = np.ascontiguousarray(texture, np.uint8)
+        self.L.ref_om_add_texture(self.om, texname.encode(), C.c_int32(tex.shape[1]), C.c_int32(tex.shape[0]), _p(tex, _u8p))
+        self.L.ref_om_add_textured_object(self.om, name.encode(), C.c_uint32(pts.shape[0]), _p(pts, _f32p), _p(tc, _f32p), texname.encode())
+
     def clone(self, src, dst): self.L.ref_om_clone(self.om, src.encode(), dst.encode())
     def set_color(self, name, rgb): self.L.ref_om_set_color(self.om, name.encode(), *[float(x) for x in rgb])
     def set_props(self, name, p): self.L.ref_om_set_props(self.om, name.encode(), *[float(x) for x in p])

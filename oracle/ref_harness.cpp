@@ -105,6 +105,27 @@ void ref_om_add_object(void* om_, const char* name, uint32_t n, const float* poi
     om->objTriangles[name] = tris;
 }
 
+// Array-fed textured object: what loadObjFile leaves behind for a textured mesh (Object.cpp:98-161): integer texel
+// coordinates per vertex, textureName on every triangle, the decoded texture in textureData / textureDimensions.
+void ref_om_add_texture(void* om_, const char* texname, int32_t w, int32_t h, const uint8_t* rgb) {
+    ObjectManager* om = (ObjectManager*)om_;
+    unsigned char* data = (unsigned char*)malloc((size_t)w * h * 3);      // stbi_load mallocs too; never freed, as in the reference
+    std::memcpy(data, rgb, (size_t)w * h * 3);
+    om->textureData[texname] = data;
+    om->textureDimensions[texname] = glm::ivec2(w, h);
+}
+void ref_om_add_textured_object(void* om_, const char* name, uint32_t n, const float* points, const float* texcoord /* n x 6 */, const char* texname) {
+    ObjectManager* om = (ObjectManager*)om_;
+    ref_om_add_object(om_, name, n, points);
+    std::vector<Triangle>& tris = om->objTriangles[name];
+    for (uint32_t i = 0; i < n; i++) {
+        tris[i].colorOneCoordinate = glm::vec2(texcoord[i*6], texcoord[i*6+1]);
+        tris[i].colorTwoCoordinate = glm::vec2(texcoord[i*6+2], texcoord[i*6+3]);
+        tris[i].colorThreeCoordinate = glm::vec2(texcoord[i*6+4], texcoord[i*6+5]);
+        tris[i].textureName = texname;
+    }
+}
+
 // Clone as main() does it (simple_raytracer.cpp:565,597,644): triangles only; colour/material are
 // whatever unordered_map::operator[] default-inserts later unless set explicitly.
 void ref_om_clone(void* om_, const char* src, const char* dst) {

@@ -36,6 +36,27 @@ int srth_om_add_object(void* om_, const char* name, uint32_t n, const float* poi
         om->setTriangles(name, tris);
     })
 }
+// Array-fed textured object: the state loadObjFile leaves for a textured mesh (Object.cpp:98-161)
+int srth_om_add_texture(void* om_, const char* texname, int32_t w, int32_t h, const uint8_t* rgb) {
+    GUARD({
+        ObjectManager* om = (ObjectManager*)om_;
+        Texture t; t.dim.x = w; t.dim.y = h; t.rgb.assign(rgb, rgb + (size_t)w * h * 3);
+        om->textureData[texname] = std::move(t);
+    })
+}
+int srth_om_add_textured_object(void* om_, const char* name, uint32_t n, const float* points, const float* texcoord, const char* texname) {
+    int rc = srth_om_add_object(om_, name, n, points);
+    if (rc) return rc;
+    GUARD({
+        std::vector<Triangle>& tris = ((ObjectManager*)om_)->objTriangles[name];
+        for (uint32_t i = 0; i < n; i++) {
+            tris[i].colorOneCoordinate = vec2(texcoord[i * 6], texcoord[i * 6 + 1]);
+            tris[i].colorTwoCoordinate = vec2(texcoord[i * 6 + 2], texcoord[i * 6 + 3]);
+            tris[i].colorThreeCoordinate = vec2(texcoord[i * 6 + 4], texcoord[i * 6 + 5]);
+            tris[i].textureName = texname;
+        }
+    })
+}
 // objTriangles[dst] = getTriangles(src), as main() clones objects (simple_raytracer.cpp:565,597,644)
 int srth_om_clone(void* om_, const char* src, const char* dst) {
     GUARD({ ObjectManager* om = (ObjectManager*)om_; std::vector<Triangle> t = om->getTriangles(src); om->objTriangles[dst] = t; })

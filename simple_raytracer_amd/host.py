@@ -33,6 +33,8 @@ def load():
             getattr(L, fn).argtypes = [C.c_void_p, C.c_char_p]
         L.srth_om_add_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p]
         L.srth_om_clone.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.srth_om_add_texture.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _u8p]
+        L.srth_om_add_textured_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p, _f32p, C.c_char_p]
         L.srth_om_set_color.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
         L.srth_om_set_props.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
         L.srth_om_transform.argtypes = [C.c_void_p, C.c_char_p, _f32p]
@@ -149,6 +151,12 @@ class ObjectManager:
     def add_object(self, name, points):
         pts = _f(points).reshape(-1, 12)
         _ok(self.L.srth_om_add_object(self.om, name.encode(), pts.shape[0], _p(pts)))
+
+    def add_textured_object(self, name, points, texcoord, texname, texture):
+        pts, tc = _f(points).reshape(-1, 12), _f(texcoord).reshape(-1, 6)
+        tex = np.ascontiguousarray(texture, np.uint8)
+        _ok(self.L.srth_om_add_texture(self.om, texname.encode(), tex.shape[1], tex.shape[0], _p(tex, _u8p)))
+        _ok(self.L.srth_om_add_textured_object(self.om, name.encode(), pts.shape[0], _p(pts), _p(tc), texname.encode()))
 
     def clone(self, src, dst): _ok(self.L.srth_om_clone(self.om, src.encode(), dst.encode()))
     def setColor(self, name, rgb): _ok(self.L.srth_om_set_color(self.om, name.encode(), *[float(x) for x in rgb]))

@@ -32,7 +32,7 @@ import scenes                              # noqa: E402
 
 M = po.RefMat
 BG = np.array(abi.REFERENCE_BACKGROUND, np.int32)
-REF_OBJ = {"cube": "cube.obj", "sphere": "sphere.obj", "bunny": "./obj/stanford-bunny.obj"}
+REF_OBJ = {"cube": "cube.obj", "sphere": "sphere.obj", "bunny": "./obj/stanford-bunny.obj", "tree": "./obj/tree/tree.obj"}
 
 
 def sha(a):
@@ -48,7 +48,15 @@ def export_mesh(key):
     f = inv.astype(np.int32).reshape(-1, 3)
     assert np.array_equal(uv[f], pts[..., :3])
     os.makedirs(os.path.join(HERE, "meshes"), exist_ok=True)
-    np.savez_compressed(os.path.join(HERE, "meshes", key + ".npz"), v=uv.astype(np.float32), f=f)
+    extra = {}
+    tc, col, ht, nrm = s.tri_attrs(REF_OBJ[key])
+    if ht.any():      # textured mesh: the loader's integer texel coordinates and the texture as stb_image decoded it
+        assert ht.all() and tc.max() < 65536 and np.all(tc == np.floor(tc))
+        texname = s.tri_texture_name(REF_OBJ[key], 0)
+        extra = dict(texcoord=tc.astype(np.uint16), texture_name=np.array(texname), texture=s.texture(texname))
+    np.savez_compressed(os.path.join(HERE, "meshes", key + ".npz"), v=uv.astype(np.float32), f=f, **extra)
+    if extra:
+        return {"points": pts, "texcoord": tc, "texture_name": texname, "texture": extra["texture"]}
     return pts
 
 
@@ -57,6 +65,7 @@ class RefBuilder:
     def __init__(self, real_loader=True, meshes=None):
         self.s = po.RefScene(); self.real = real_loader; self.meshes = meshes or {}
     def add_object(self, name, pts): self.s.add_object(name, pts)
+    def add_textured_object(self, name, pts, tc, texname, tex): self.s.add_textured_object(name, pts, tc, texname, tex)
     def clone(self, a, b): self.s.clone(a, b)
     def set_color(self, n, c): self.s.set_color(n, c)
     def set_props(self, n, p): self.s.set_props(n, p)
@@ -103,19 +112,28 @@ def outputs(s, flat, light3, W, H, n_lights, full):
     return out
 
 
-def make_scene(name, recipe, meshes, renders, textures=None, prebuilt=None):
+def make_scene(name, recipe, meshes, renders, textures=None, prebuilt=None, compact=False):
     print("scene", name)
     s = prebuilt if prebuilt is not None else replay_on_ref(recipe, meshes, real_loader=True)
     flat = s.export(textures=textures)
     if recipe is not None and prebuilt is None:
         # array-fed replay must give the identical flat scene (this is what tests replay)
         s2 = replay_on_ref(recipe, meshes, real_loader=False)
-        f2 = s2.export()
+        f2 = s2.export(textures=textures)
         for k in abi.FlatScene.ARRAYS:
             a, b = getattr(flat, k), getattr(f2, k)
             assert (a is None and b is None) or np.array_equal(a, b), (name, k)
         assert flat.names == f2.names
-    d = flat.to_npz_dict()
+    if compact:
+        # big scene: keep the recipe, the object order and a sha256 of every flat array of the reference's export; tests
+        # rebuild the scene with the host mirror (proven to reproduce the reference's trees) and check the hashes
+        d = {"scene_names": np.array(flat.names, dtype="U")}
+        for k in abi.FlatScene.ARRAYS:
+            if getattr(flat, k) is not None:
+                d["sha_scene_" + k] = np.array(sha(getattr(flat, k)))
+        d["scene_counts"] = np.array([flat.n_objects, flat.n_nodes, flat.n_tris, flat.n_textures])
+    else:
+        d = flat.to_npz_dict()
     d["recipe"] = np.array(recipe.to_json() if recipe is not None else "")
     d["light"] = np.array(recipe.light if recipe is not None else renders[0][4], np.float32)
     for (W, H, nl, full, *rest) in renders:
@@ -297,6 +315,10 @@ def main():
     make_scene("cube_ground", scenes.cube_over_ground(M), meshes, [(240, 135, 1, True), (1920, 1080, 1, False)])
     make_scene("ground_bunny", scenes.ground_bunny(M), meshes, [(192, 108, 1, True), (96, 54, 4, True), (1920, 1080, 1, False)])
     make_texquad()
+    # the scene of the reference's checked-in main() (minus the cats, a missing blob) at the reference's own 600x400
+    tex = meshes["tree"]["texture_name"]
+    make_scene("main_nocats", scenes.main_scene_no_cats(M, 0.0), meshes, [(600, 400, 1, False), (150, 100, 4, True)],
+               textures={"./obj/tree/tree.obj": tex, "./obj/tree/tree.obj1": tex, "./obj/tree/tree.obj2": tex}, compact=True)
 
 
 if __name__ == "__main__":

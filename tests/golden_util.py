@@ -10,7 +10,7 @@ import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-SCENES = ["cube", "sphere", "cubes4_a0", "cubes4_a40", "spheres6", "cube_ground", "ground_bunny", "texquad"]
+SCENES = ["cube", "sphere", "cubes4_a0", "cubes4_a40", "spheres6", "cube_ground", "ground_bunny", "texquad", "main_nocats"]
 
 
 def sha(a):
@@ -29,12 +29,29 @@ class GoldenScene:
     def __init__(self, name):
         self.name = name
         self.z = np.load(os.path.join(GOLDEN, f"scene_{name}.npz"))
-        self.flat = abi.FlatScene.from_npz_dict(self.z)
         self.light = self.z["light"]
         rj = str(self.z["recipe"])
         self.recipe = scenes.Recipe.from_json(rj) if rj else None
+        self.compact = "scene_node_min" not in self.z.files
+        self._flat = None if self.compact else abi.FlatScene.from_npz_dict(self.z)
         self.renders = sorted({(int(m.group(1)), int(m.group(2)), int(m.group(3)))
                                for m in (re.match(r"(\d+)x(\d+)_L(\d+)_hit_id$", k) for k in self.z.files) if m})
+
+    @property
+    def flat(self):
+        """The reference's flat scene.  Big scenes are stored as recipe + sha256 of every array of the reference's export:
+        they are rebuilt with the host-side mirror (C++, CPU) and must hash to the reference's arrays."""
+        if self._flat is None:
+            from simple_raytracer_amd import build, host
+            build.build_host()
+            f = host.build_flat_scene(self.recipe, {k: load_mesh(k) for k in self.recipe.meshes})
+            assert f.names == [str(x) for x in self.z["scene_names"]], "object order differs from the reference's"
+            for k in abi.FlatScene.ARRAYS:
+                key = "sha_scene_" + k
+                if key in self.z.files:
+                    assert sha(getattr(f, k)) == str(self.z[key]), f"host mirror's {k} differs from the reference's export"
+            self._flat = f
+        return self._flat
 
     def out(self, W, H, L, key):
         k = f"{W}x{H}_L{L}_{key}"

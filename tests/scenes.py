@@ -55,7 +55,10 @@ class Recipe:
 
 def apply_op(builder, op, meshes):
     k = op[0]
-    if k == "load": builder.add_object(op[1], meshes[op[2]])
+    if k == "load":
+        m = meshes[op[2]]
+        if isinstance(m, dict): builder.add_textured_object(op[1], m["points"], m["texcoord"], m["texture_name"], m["texture"])
+        else: builder.add_object(op[1], m)
     elif k == "clone": builder.clone(op[1], op[2])
     elif k == "color": builder.set_color(op[1], op[2])
     elif k == "props": builder.set_props(op[1], op[2])
@@ -125,6 +128,39 @@ def four_cubes(M, angle=0.0):
     for nm in ["cube.obj", "cube1.obj", "cube2.obj", "cube3.obj"]:
         r.transform(nm, inv)
     for nm in ["cube.obj", "cube1.obj", "cube2.obj", "cube3.obj"]:
+        r.bvh(nm)
+    r.light = M.mul_vec4(inv, LIGHT_DEFAULT)[:3]
+    return r
+
+
+def main_scene_no_cats(M, angle=0.0):
+    """The scene the reference's checked-in main() builds (simple_raytracer.cpp:546-618: ground cube, bunny, three
+    textured trees) WITHOUT the two cats, whose cat.obj is a missing blob.  Tree clones copy the triangles and the
+    material of tree.obj (specular strength set to 0, :595-600); each object goes into view space (:558 etc.)."""
+    r = Recipe(); inv = _orbit_view(M, 50.0, angle, -50.0, 30.0)
+    r.load("./obj/cube.obj", "cube")
+    r.color("./obj/cube.obj", (0.0, 1.0, 0.0))
+    r.transform("./obj/cube.obj", M.scale(35.0, 35.0, 35.0))
+    r.transform("./obj/cube.obj", M.translate(0.0, 10.0, 0.0))
+    r.transform("./obj/cube.obj", inv)
+    r.bvh("./obj/cube.obj")
+    r.load("./obj/stanford-bunny.obj", "bunny")
+    r.color("./obj/stanford-bunny.obj", (0.9, 0.9, 0.9))
+    r.transform("./obj/stanford-bunny.obj", M.scale(50.0, 50.0, 50.0))
+    r.transform("./obj/stanford-bunny.obj", M.rotx(M.radians(181.0)))
+    r.transform("./obj/stanford-bunny.obj", M.roty(M.radians(90.0)))
+    r.transform("./obj/stanford-bunny.obj", M.translate(25.0, -23.0, 0.0))
+    r.transform("./obj/stanford-bunny.obj", inv)
+    r.bvh("./obj/stanford-bunny.obj")
+    r.load("./obj/tree/tree.obj", "tree")
+    r.props("./obj/tree/tree.obj", (0.2, 0.0, 15.0))                       # objProperties[...].y = 0.0f (:595)
+    for nm in ("./obj/tree/tree.obj1", "./obj/tree/tree.obj2"):
+        r.clone("./obj/tree/tree.obj", nm); r.props(nm, (0.2, 0.0, 15.0))    # :597-600
+    for nm, sc, z in (("./obj/tree/tree.obj", 0.03, -25.0), ("./obj/tree/tree.obj1", 0.035, 0.0), ("./obj/tree/tree.obj2", 0.03, 25.0)):
+        r.transform(nm, M.scale(sc, sc, sc))
+        r.transform(nm, M.rotx(M.radians(-90.0)))
+        r.transform(nm, M.translate(-6.0, -25.0, z))
+        r.transform(nm, inv)
         r.bvh(nm)
     r.light = M.mul_vec4(inv, LIGHT_DEFAULT)[:3]
     return r
@@ -217,8 +253,12 @@ def soup(n_tris, n_objects=4, **kw):
 
 
 def mesh_points(npz):
-    """(verts[n,3], faces[m,3]) -> points[m,3,4] with w = 1 (Object.cpp:82-89)."""
+    """(verts[n,3], faces[m,3]) -> points[m,3,4] with w = 1 (Object.cpp:82-89); textured meshes come back as a dict
+    with the loader's per-vertex integer texel coordinates and the decoded texture (Object.cpp:113-119,57)."""
     v, f = npz["v"], npz["f"]
     pts = np.ones((f.shape[0], 3, 4), np.float32)
     pts[:, :, :3] = v[f]
+    if "texcoord" in npz.files:
+        return {"points": pts, "texcoord": npz["texcoord"].astype(np.float32), "texture_name": str(npz["texture_name"]),
+                "texture": npz["texture"]}
     return pts

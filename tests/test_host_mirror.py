@@ -41,7 +41,17 @@ def test_transformation_factories_match_reference(host):
     assert np.array_equal(bits(np.stack([T.mul_vec4(k["tf_view_inv"][i], k["tf_vec"][i]) for i in range(10)])), bits(k["tf_mulvec"]))
 
 
-@pytest.mark.parametrize("name", [s for s in gu.SCENES if s != "texquad"])
+def test_builder_reproduces_reference_main_scene(host):
+    """The scene of the reference's checked-in main() (minus the cats): 177 k triangles in 5 objects, three of them textured
+    clones.  Stored as sha256 of every array of the reference's export; GoldenScene.flat rebuilds it with the mirror and
+    asserts the hashes (object order, trees, leaf order, transformed points, texel coordinates, texture bytes)."""
+    g = gu.GoldenScene("main_nocats")
+    f = g.flat
+    assert (f.n_objects, f.n_nodes, f.n_tris, f.n_textures) == tuple(int(x) for x in g.z["scene_counts"])
+    assert f.n_tris == 177463 and f.n_textures == 1 and (f.tri_tex >= 0).sum() == 3 * 36000
+
+
+@pytest.mark.parametrize("name", [s for s in gu.SCENES if s not in ("texquad", "main_nocats")])
 def test_builder_reproduces_reference_flat_scene(host, name):
     """Replay the scene recipe (same transforms, same createBoundingHierarchy calls) on the host mirror:
     object order, tree topology, boxes, leaf order and transformed points equal the reference's."""
