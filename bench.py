@@ -141,7 +141,8 @@ def main():
             graphs = []
             for slot in range(SLOTS):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
+                # thread_local: RCCL's watchdog thread may query events while this thread captures
+                with torch.cuda.graph(gph, capture_error_mode="thread_local"):
                     render_frames(p_quiet, slot)
                 graphs.append(gph)
         except Exception as e:                                         # capture is an optimisation, not a requirement
