@@ -127,6 +127,10 @@ def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libsrt_ref.so"))
 
 
+def ref_adapter_available():
+    return ref_available() and os.path.exists(os.path.join(_HERE, "_ref", "libsrt_ref_adapter.so"))
+
+
 def ref_lib():
     global _ref
     if _ref is None:
@@ -310,6 +314,20 @@ class RefScene:
         rgb = np.empty((H, W, 3), np.float32)
         n = self.L.ref_render(self.om, C.c_uint32(W), C.c_uint32(H), _p(light4, _f32p), _p(rgb, _f32p))
         return rgb, n
+
+    def render_hip(self, W, H, light4):
+        """The SAME ObjectManager through the reference-side adapter of INTEGRATION.md (oracle/srt_adapter.cpp) -> C ABI ->
+        HIP kernels.  Needs a GPU.  Same return shape as render()."""
+        path = os.path.join(_HERE, "_ref", "libsrt_ref_adapter.so")
+        A = C.CDLL(path)
+        A.srt_adapter_render.restype = C.c_longlong
+        light4 = np.ascontiguousarray(light4, np.float32)
+        rgb = np.empty((H, W, 3), np.float32)
+        err = C.create_string_buffer(512)
+        n = A.srt_adapter_render(self.om, C.c_uint32(W), C.c_uint32(H), _p(light4, _f32p), _p(rgb, _f32p), err, C.c_uint32(512))
+        if n < 0:
+            raise RuntimeError("adapter: " + err.value.decode())
+        return rgb, int(n)
 
     def trace(self, W, H, light3, n_lights):
         """Closest-hit ids / t / softShadow(n_lights) / pre-tone-map sums via the reference's leaf functions."""

@@ -388,3 +388,23 @@ def test_device_pow_against_library_and_host(srt):
     sub = slice(0, 40000)
     host = np.array([libm.powf(float(a), float(b)) for a, b in zip(x[sub], y[sub])], np.float32)
     assert (bits(fast[sub]) != bits(host)).mean() < 3e-3 and np.abs(fast[sub] - host).max() < 1e-6
+
+
+def test_reference_object_manager_through_the_adapter(srt, oracle):
+    """End to end with the reference's OWN data structures: its ObjectManager (compiled reference code, oracle/_ref) is
+    filled by the scene recipe, then rendered twice -- by the reference's CPU path and, through the binding of
+    INTEGRATION.md option A (oracle/srt_adapter.cpp -> include/srt.h), by the HIP kernels.  Same (px, py, rgb) list."""
+    if not oracle.ref_adapter_available():
+        pytest.skip("oracle/_ref not built (it is built in the container that has the reference sources)")
+    for name, (W, H) in (("cubes4_a40", (200, 150)), ("ground_bunny", (192, 108))):
+        g = gu.GoldenScene(name)
+        s = oracle.RefScene()
+        g.recipe.replay(s, {k: gu.load_mesh(k) for k in g.recipe.meshes})
+        light4 = list(g.light) + [1.0]
+        cpu, n_cpu = s.render(W, H, light4)            # the reference itself, on this box's host
+        hip, n_hip = s.render_hip(W, H, light4)        # the same ObjectManager through the C ABI
+        assert abs(n_cpu - n_hip) <= 2
+        d = np.abs(cpu - hip)
+        assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2, "HIP image differs from the reference's own render"
+        q = hip.astype(np.int32); q[q.sum(-1) == 0] = abi.REFERENCE_BACKGROUND
+        check_rgb8(q.astype(np.uint8), g.out(W, H, 1, "rgb8"))

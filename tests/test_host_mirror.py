@@ -142,3 +142,24 @@ def test_texture_decoders_and_textured_loader(host, tmp_path, oracle):
         r = oracle.RefScene(); r.load_obj(name, cwd=str(tmp_path))
         rtc, rcol, rht, _ = r.tri_attrs(name)
         assert np.array_equal(bits(tc), bits(rtc)) and np.array_equal(bits(col), bits(rcol)) and np.array_equal(ht, rht)
+
+
+def test_integration_adapter_compiles_against_the_reference(tmp_path):
+    """INTEGRATION.md option A: the adapter a reference maintainer adds (their ObjectManager / Node / Triangle types ->
+    srt_scene_desc -> srt_render) compiles against the reference's own headers.  Build container only."""
+    import re
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "Object.h")):
+        pytest.skip("reference sources not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```cpp\n(// srt_adapter\.cpp.*?)```", md, re.S).group(1)
+    built = open(os.path.join(root, "oracle", "srt_adapter.cpp")).read()
+    assert code in built, "oracle/srt_adapter.cpp (what the GPU tests run) and the block in INTEGRATION.md differ"
+    src = tmp_path / "srt_adapter.cpp"
+    src.write_text(code)
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + ref, "-I" + ref + "/library/glm-master/glm", "-I" + ref + "/library/tinyobjloader",
+           "-I" + os.path.join(root, "include"), str(src)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
