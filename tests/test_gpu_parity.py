@@ -408,3 +408,54 @@ def test_reference_object_manager_through_the_adapter(srt, oracle):
         assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2, "HIP image differs from the reference's own render"
         q = hip.astype(np.int32); q[q.sum(-1) == 0] = abi.REFERENCE_BACKGROUND
         check_rgb8(q.astype(np.uint8), g.out(W, H, 1, "rgb8"))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_scenes_match_oracle(srt, oracle, seed):
+    """Scenes built to hit the tie-breaks and the degenerate arithmetic: identical triangles in several objects (equal t
+    across objects -> lowest id), axis-aligned quads (flat boxes, x/0 on the i = 0 column and j = 0 row), coordinates from
+    1e-3 to 1e6, slivers, triangles through the camera origin.  Shipped kernels (filtered slab test) and the exact-divide
+    build must both equal the oracle bit for bit on ids and t."""
+    from simple_raytracer_amd import host
+    import scenes
+    rng = np.random.default_rng(seed)
+    scale = [1.0, 1e-3, 3e5][seed - 1]
+    n_obj = 6
+    recipe = scenes.Recipe(); meshes = {}
+    shared = None
+    for k in range(n_obj):
+        n = int(rng.integers(1, 90))
+        c = rng.uniform(-120, 120, (n, 1, 3)); c[..., 2] += 320
+        pts = np.ones((n, 3, 4), np.float32)
+        pts[..., :3] = (c + rng.uniform(-60, 60, (n, 3, 3))) * scale
+        # axis-aligned quads at integer-friendly depths: flat boxes and exact ties between their two triangles' edges
+        m = min(n, 6)
+        for q in range(0, m - 1, 2):
+            z = float(rng.integers(200, 400)) * scale; x0, x1 = sorted(rng.integers(-100, 100, 2) * scale); y0, y1 = sorted(rng.integers(-80, 80, 2) * scale)
+            pts[q, :, :3] = [[x0, y0, z], [x1, y0, z], [x1, y1, z]]
+            pts[q + 1, :, :3] = [[x0, y0, z], [x1, y1, z], [x0, y1, z]]
+        if n > 8:
+            pts[7, :, :3] = [[-50 * scale, 0, 100 * scale], [50 * scale, 0, 100 * scale], [0, 0, 900 * scale]]     # plane through the origin
+            pts[8, 2, :3] = pts[8, 0, :3] + (pts[8, 1, :3] - pts[8, 0, :3]) * np.float32(1 + 1e-6)                # sliver
+        if k == 1:
+            shared = pts[: max(1, n // 2)].copy()
+        if k in (3, 4) and shared is not None:
+            pts = np.concatenate([pts, shared])          # the same triangles again in other objects: equal t across objects
+        meshes[f"m{k}"] = pts
+        recipe.load(f"obj{k}", f"m{k}"); recipe.color(f"obj{k}", rng.uniform(0, 1, 3)); recipe.bvh(f"obj{k}")
+    recipe.light = tuple(float(x) for x in rng.uniform(-400, 400, 3) * scale)
+    flat = host.build_flat_scene(recipe, meshes)
+    ds = srt.DeviceScene(flat)
+    W, H, L = 161, 121, 3
+    focal = 400.0 * (1.0 if scale == 1.0 else 1.0)
+    p = abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK)
+    c = oracle.render(flat, p)
+    assert (c["hit_id"] >= 0).sum() > 200
+    for variant in (0, 4, 3):
+        o = ds.render(abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8)))
+        assert np.array_equal(o["hit_id"], c["hit_id"]), f"variant {variant}: {int((o['hit_id'] != c['hit_id']).sum())} hit ids differ"
+        assert np.array_equal(bits(o["t"]), bits(c["t"]))
+        fin = np.isfinite(c["rgb_linear"]).all(-1)
+        assert np.abs(o["rgb_linear"][fin] - c["rgb_linear"][fin]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"][fin]).max()))
+        assert o["stats"]["node_tests_primary"] == c["stats"]["node_tests_primary"] and o["stats"]["tri_tests_primary"] == c["stats"]["tri_tests_primary"]
+        assert o["stats"]["node_tests_shadow"] == c["stats"]["node_tests_shadow"]
