@@ -49,7 +49,7 @@ def build_hip(force=False, verbose=False):
 
 
 LIB_HOST = os.path.join(HERE, "libsrt_host.so")
-HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread"]
 
 
 def build_host(force=False, verbose=False):

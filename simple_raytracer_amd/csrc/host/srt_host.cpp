@@ -8,6 +8,12 @@
 #include "srt_host.h"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +26,72 @@
 #include <zlib.h>
 
 namespace srt_host {
+
+namespace {
+// Worker threads for the per-frame host stages (transform, subtree builds, flatten, ImageData).  Created once and
+// kept (a stage is a few milliseconds: threads started per call spend most of it being created and migrated to a
+// free core); idle workers spin briefly, then sleep.
+// Leaked on purpose: workers blocked at process exit die with the process, no static-destructor joins.
+class BuildPool {
+public:
+    static BuildPool& get() { static BuildPool* p = new BuildPool(); return *p; }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> g(m_); q_.push_back(std::move(f)); }
+        queued_.fetch_add(1, std::memory_order_release);
+        cv_.notify_one();
+    }
+    bool run_one() {                       // run one queued task on the calling thread
+        if (queued_.load(std::memory_order_acquire) == 0) return false;
+        std::function<void()> f;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (q_.empty()) return false;
+            f = std::move(q_.front()); q_.pop_front();
+            queued_.fetch_sub(1, std::memory_order_relaxed);
+        }
+        f();
+        return true;
+    }
+    unsigned workers() const { return n_; }
+private:
+    BuildPool() {
+        unsigned hc = std::thread::hardware_concurrency();
+        n_ = hc > 1 ? (hc > 16 ? 15 : hc - 1) : 0;
+        for (unsigned i = 0; i < n_; i++) std::thread([this] { loop(); }).detach();
+    }
+    void loop() {
+        for (;;) {
+            bool ran = false;
+            for (int spin = 0; spin < 4000 && !ran; spin++) { ran = run_one(); if (!ran) std::this_thread::yield(); }
+            if (ran) continue;
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [this] { return !q_.empty(); });
+        }
+    }
+    std::mutex m_; std::condition_variable cv_; std::deque<std::function<void()>> q_;
+    std::atomic<int> queued_{0};
+    unsigned n_ = 0;
+};
+
+// fn(begin, end) over [0, n) in chunks of at least `grain`, on the pool plus the calling thread
+void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
+    BuildPool& pool = BuildPool::get();
+    size_t chunks = grain ? (n + grain - 1) / grain : 1;
+    if (chunks > pool.workers() + 1) chunks = pool.workers() + 1;
+    if (chunks <= 1) { if (n) fn(0, n); return; }
+    const size_t step = (n + chunks - 1) / chunks;
+    std::atomic<int> pending{0};
+    for (size_t c = 1; c < chunks; c++) {
+        const size_t b = c * step, e = (b + step < n) ? b + step : n;
+        if (b >= e) continue;
+        pending.fetch_add(1, std::memory_order_relaxed);
+        pool.submit([&fn, &pending, b, e] { fn(b, e); pending.fetch_sub(1, std::memory_order_release); });
+    }
+    fn(0, step < n ? step : n);
+    while (pending.load(std::memory_order_acquire) > 0)
+        if (!pool.run_one()) std::this_thread::yield();
+}
+} // namespace
 
 // ------------------------------------------------------------------------------------------------
 // glm operations the reference's host code applies (exact op order)
@@ -401,68 +473,110 @@ vec3 ObjectManager::getColor(const std::string& objFilename) const { return objC
 
 void ObjectManager::transformTriangles(const std::string& objFilename, const mat4& matrix) {
     std::vector<Triangle>& triangles = objTriangles[objFilename];      // operator[]: creates an empty object, like the reference
-    for (Triangle& t : triangles) {
-        t.pointOne = matrix * t.pointOne;
-        t.pointTwo = matrix * t.pointTwo;
-        t.pointThree = matrix * t.pointThree;
-    }
+    parallel_for(triangles.size(), 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            Triangle& t = triangles[i];
+            t.pointOne = matrix * t.pointOne;
+            t.pointTwo = matrix * t.pointTwo;
+            t.pointThree = matrix * t.pointThree;
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
 // createBoundingHierarchy, Object.cpp:205-284.  Same tree, same leaf order as the reference builds:
-// std::sort (libstdc++ introsort) over the node's triangles with the reference's three comparators;
-// the permutation std::sort produces depends only on the comparison outcomes, so sorting indices with
-// the same keys gives the reference's order without copying 152-byte Triangles around.
+// std::sort (libstdc++ introsort) over the node's triangles with the reference's three comparators.
+// The permutation std::sort produces depends only on the comparison outcomes (first vertices are shared
+// between triangles, so equal keys are the rule, and their order is introsort's), so the node's
+// (key, index) pairs are sorted with the same '<' on the key: the reference's order without moving
+// 152-byte Triangles.  The tree's shape depends only on the triangle count (halve while > 8), so every
+// node's pre-order slot is known before it is built and disjoint subtrees are built by parallel threads.
+// Per-frame cost is what matters here: the reference re-transforms and re-builds every frame
+// (simple_raytracer.cpp:534-618), and at HIP render times the build is the frame.
 // ------------------------------------------------------------------------------------------------
 namespace {
+struct KeyIdx { float key; uint32_t idx; };
+
 struct Builder {
-    const std::vector<Triangle>& tris;
     ObjectManager::Hierarchy& h;
+    std::vector<float> p1;          // pointOne xyz per triangle (the sort keys)
+    std::vector<float> lo, hi;      // per triangle: first minimum / maximum over its three points, per axis
+    std::vector<KeyIdx> scratch;    // one slot per triangle; a node sorts its own [first, first + count) range
+    std::atomic<int> pending{0};    // subtree tasks handed to the pool and not finished yet
+
+    // nodes of the subtree of a CHILD holding c triangles (a child is split only while it holds > 8, :261-267)
+    static uint32_t subtree(uint32_t c) { return c > 8 ? 1 + subtree(c / 2) + subtree(c - c / 2) : 1; }
 
     void bounds(uint32_t first, uint32_t count, vec3& mn, vec3& mx) const {       // calculateBoundingBoxes :205-221
-        mn = vec3(FLT_MAX, FLT_MAX, FLT_MAX); mx = vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+        float a[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, b[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
         for (uint32_t k = 0; k < count; k++) {
-            const Triangle& t = tris[h.order[first + k]];
-            const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
-            for (int j = 0; j < 3; j++) for (int a = 0; a < 3; a++) { float v = (*p[j])[a]; if (v < mn[a]) mn[a] = v; }   // glm::min(x,y) = y<x ? y : x
-            for (int j = 0; j < 3; j++) for (int a = 0; a < 3; a++) { float v = (*p[j])[a]; if (mx[a] < v) mx[a] = v; }   // glm::max(x,y) = x<y ? y : x
+            const uint32_t t = h.order[first + k];
+            // glm::min(x,y) = y<x ? y : x keeps the earlier of equal values (+0 / -0): reducing a triangle's three
+            // points first and then folding keeps the same element as the reference's point-by-point fold
+            for (int c = 0; c < 3; c++) { const float v = lo[3 * t + c]; if (v < a[c]) a[c] = v; }
+            for (int c = 0; c < 3; c++) { const float v = hi[3 * t + c]; if (b[c] < v) b[c] = v; }
         }
+        mn = vec3(a[0], a[1], a[2]); mx = vec3(b[0], b[1], b[2]);
     }
 
-    void split(int32_t node) {                                                     // splitTrianglesForBox :225-272
+    void split(int32_t node, int depth) {                                          // splitTrianglesForBox :225-272
         const vec3 mn = h.nodes[node].minBox, mx = h.nodes[node].maxBox;
         const uint32_t first = h.nodes[node].first, n = h.nodes[node].count;
         const float sx = std::fabs(mx.x - mn.x), sy = std::fabs(mx.y - mn.y), sz = std::fabs(mx.z - mn.z);
-        auto b = h.order.begin() + first, e = b + n;
-        if (sx > sy && sx > sz)      std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.x < tris[c].pointOne.x; });
-        else if (sy > sx && sy > sz) std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.y < tris[c].pointOne.y; });
-        else                         std::sort(b, e, [&](uint32_t a, uint32_t c) { return tris[a].pointOne.z < tris[c].pointOne.z; });
+        const int axis = (sx > sy && sx > sz) ? 0 : ((sy > sx && sy > sz) ? 1 : 2);
+        KeyIdx* b = scratch.data() + first;
+        for (uint32_t k = 0; k < n; k++) { const uint32_t t = h.order[first + k]; b[k].key = p1[3 * t + axis]; b[k].idx = t; }
+        std::sort(b, b + n, [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; });
+        for (uint32_t k = 0; k < n; k++) h.order[first + k] = b[k].idx;
         const uint32_t nl = n / 2, nr = n - nl;
-        Node L, R;
+        const int32_t li = node + 1, ri = li + (int32_t)subtree(nl);               // DFS pre-order slots
+        h.nodes[node].left = li; h.nodes[node].right = ri;
+        Node& L = h.nodes[li]; Node& R = h.nodes[ri];
         L.first = first; L.count = nl; bounds(L.first, L.count, L.minBox, L.maxBox);
         R.first = first + nl; R.count = nr; bounds(R.first, R.count, R.minBox, R.maxBox);
-        const int32_t li = (int32_t)h.nodes.size();
-        h.nodes[node].left = li; h.nodes.push_back(L);
-        if (nl > 8) split(li);                                                     // triangleSizeStop = 8 (:261)
-        const int32_t ri = (int32_t)h.nodes.size();
-        h.nodes[node].right = ri; h.nodes.push_back(R);
-        if (nr > 8) split(ri);
+        // the two halves touch disjoint ranges of order / scratch and disjoint node slots
+        if (nl > 8 && nr > 8 && depth < PAR_DEPTH && n >= PAR_MIN && BuildPool::get().workers()) {
+            pending.fetch_add(1, std::memory_order_relaxed);
+            BuildPool::get().submit([this, li, depth] { split(li, depth + 1); pending.fetch_sub(1, std::memory_order_release); });
+            split(ri, depth + 1);
+        } else {
+            if (nl > 8) split(li, depth + 1);                                      // triangleSizeStop = 8 (:261)
+            if (nr > 8) split(ri, depth + 1);
+        }
     }
+    static constexpr int PAR_DEPTH = 5;          // up to 32 concurrent subtrees
+    static constexpr uint32_t PAR_MIN = 2048;    // not worth a task below this
 };
 } // namespace
 
 void ObjectManager::createBoundingHierarchy(const std::string& objFilename) {
     std::vector<Triangle>& triangles = objTriangles[objFilename];
+    const uint32_t n = (uint32_t)triangles.size();
     Hierarchy h;
-    h.order.resize(triangles.size());
-    for (uint32_t i = 0; i < triangles.size(); i++) h.order[i] = i;
-    Builder b{ triangles, h };
-    Node root; root.first = 0; root.count = (uint32_t)triangles.size();
-    b.bounds(0, root.count, root.minBox, root.maxBox);
-    minBox[objFilename] = root.minBox; maxBox[objFilename] = root.maxBox;        // :280
-    h.nodes.reserve(triangles.size() / 2 + 8);
-    h.nodes.push_back(root);
-    b.split(0);                                                                  // the root is always split (:282)
+    h.order.resize(n);
+    Builder b{ h, {}, {}, {}, {}, {} };
+    b.p1.resize(3 * (size_t)n); b.lo.resize(3 * (size_t)n); b.hi.resize(3 * (size_t)n); b.scratch.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        h.order[i] = i;
+        const Triangle& t = triangles[i];
+        const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
+        for (int c = 0; c < 3; c++) {
+            b.p1[3 * i + c] = t.pointOne[c];
+            float lo = (*p[0])[c], hi = (*p[0])[c];
+            for (int j = 1; j < 3; j++) { const float v = (*p[j])[c]; if (v < lo) lo = v; if (hi < v) hi = v; }
+            b.lo[3 * i + c] = lo; b.hi[3 * i + c] = hi;
+        }
+    }
+    const uint32_t nl = n / 2;
+    h.nodes.resize(1 + (size_t)Builder::subtree(nl) + Builder::subtree(n - nl));   // the root is always split (:282)
+    Node& root = h.nodes[0]; root.first = 0; root.count = n;
+    b.bounds(0, n, root.minBox, root.maxBox);
+    minBox[objFilename] = root.minBox; maxBox[objFilename] = root.maxBox;          // :280
+    b.split(0, 0);
+    while (b.pending.load(std::memory_order_acquire) > 0)                        // help with the queued subtrees
+        if (!BuildPool::get().run_one()) std::this_thread::yield();
+    h.triangles.resize(n);                                                       // the nodes' by-value triangles (Object.h:49)
+    parallel_for(n, 4096, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) h.triangles[k] = triangles[h.order[k]]; });
     boundingVolumeHierarchy[objFilename] = std::move(h);
 }
 
@@ -487,56 +601,76 @@ srt_scene_desc FlatScene::desc() const {
 FlatScene flattenScene(ObjectManager* om) {
     FlatScene f;
     std::unordered_map<std::string, int32_t> tex_id;
+    // pass 1 (serial, per object): slots.  Hierarchy::nodes is already DFS pre-order and its leaves cover
+    // Hierarchy::order left to right, so a triangle's flat index is its object's base + its position in order.
+    struct Obj { const std::vector<Triangle>* tris; const ObjectManager::Hierarchy* h; int32_t node_base; int32_t tri_base; int32_t id; };
+    std::vector<Obj> objs;
+    size_t nt = 0, nn = 0;
     for (const auto& pair : om->objTriangles) {                 // the iteration order rayIntersection:409 uses
         const std::string& name = pair.first;
         auto hit = om->boundingVolumeHierarchy.find(name);
         if (hit == om->boundingVolumeHierarchy.end())
             throw std::runtime_error("object '" + name + "' has no bounding hierarchy (createBoundingHierarchy not called)");
-        const ObjectManager::Hierarchy& h = hit->second;
-        const std::vector<Triangle>& tris = pair.second;
-        const int32_t obj = (int32_t)f.obj_root.size();
-        const int32_t base = (int32_t)f.node_left.size();
+        objs.push_back({ &hit->second.triangles, &hit->second, (int32_t)nn, (int32_t)nt, (int32_t)objs.size() });
         f.names.push_back(name);
-        f.obj_root.push_back((uint32_t)base);
+        f.obj_root.push_back((uint32_t)nn);
         const vec3 c = om->objColors[name], m = om->objProperties[name];    // operator[]: default-inserts (0,0,0) like :368,439
         f.obj_color.insert(f.obj_color.end(), { c.x, c.y, c.z });
         f.obj_material.insert(f.obj_material.end(), { m.x, m.y, m.z });
-        for (const Node& n : h.nodes) {                          // Hierarchy::nodes is already DFS pre-order
-            f.node_min.insert(f.node_min.end(), { n.minBox.x, n.minBox.y, n.minBox.z });
-            f.node_max.insert(f.node_max.end(), { n.maxBox.x, n.maxBox.y, n.maxBox.z });
-            const bool leaf = n.left < 0 && n.right < 0;
-            f.node_left.push_back(leaf ? -1 : base + n.left);
-            f.node_right.push_back(leaf ? -1 : base + n.right);
-            f.node_first.push_back(leaf ? (int32_t)f.tri_obj.size() : -1);
-            f.node_count.push_back(leaf ? (int32_t)n.count : 0);
-            if (!leaf) continue;
-            for (uint32_t k = 0; k < n.count; k++) {
-                const Triangle& t = tris[h.order[n.first + k]];
-                const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
-                for (int j = 0; j < 3; j++) f.tri_points.insert(f.tri_points.end(), { p[j]->x, p[j]->y, p[j]->z, p[j]->w });
-                const vec2* tc[3] = { &t.colorOneCoordinate, &t.colorTwoCoordinate, &t.colorThreeCoordinate };
-                for (int j = 0; j < 3; j++) f.tri_texcoord.insert(f.tri_texcoord.end(), { tc[j]->x, tc[j]->y });
-                const vec3* nn[3] = { &t.normalOne, &t.normalTwo, &t.normalThree };
-                for (int j = 0; j < 3; j++) f.tri_normals.insert(f.tri_normals.end(), { nn[j]->x, nn[j]->y, nn[j]->z });
-                f.tri_obj.push_back(obj);
-                int32_t tid = -1;
-                if (!t.textureName.empty()) {
-                    auto ti = om->textureData.find(t.textureName);
-                    if (ti != om->textureData.end()) {
-                        auto known = tex_id.find(t.textureName);
-                        if (known == tex_id.end()) {
-                            tid = (int32_t)f.tex_w.size();
-                            tex_id[t.textureName] = tid;
-                            f.tex_names.push_back(t.textureName);
-                            f.tex_off.push_back((uint64_t)f.tex_rgb.size());
-                            f.tex_w.push_back((uint32_t)ti->second.dim.x); f.tex_h.push_back((uint32_t)ti->second.dim.y);
-                            f.tex_rgb.insert(f.tex_rgb.end(), ti->second.rgb.begin(), ti->second.rgb.end());
-                        } else tid = known->second;
-                    }
+        nn += hit->second.nodes.size(); nt += hit->second.triangles.size();
+    }
+    f.node_min.resize(3 * nn); f.node_max.resize(3 * nn); f.node_left.resize(nn); f.node_right.resize(nn);
+    f.node_first.resize(nn); f.node_count.resize(nn);
+    f.tri_points.resize(12 * nt); f.tri_texcoord.resize(6 * nt); f.tri_normals.resize(9 * nt); f.tri_obj.resize(nt); f.tri_tex.resize(nt);
+    for (const Obj& o : objs) {
+        const ObjectManager::Hierarchy& h = *o.h;
+        const std::vector<Triangle>& tris = *o.tris;
+        // pass 2 (serial): texture ids in first-use order over the flat triangle sequence
+        for (size_t k = 0; k < tris.size(); k++) {
+            const Triangle& t = tris[k];
+            int32_t tid = -1;
+            if (!t.textureName.empty()) {
+                auto ti = om->textureData.find(t.textureName);
+                if (ti != om->textureData.end()) {
+                    auto known = tex_id.find(t.textureName);
+                    if (known == tex_id.end()) {
+                        tid = (int32_t)f.tex_w.size();
+                        tex_id[t.textureName] = tid;
+                        f.tex_names.push_back(t.textureName);
+                        f.tex_off.push_back((uint64_t)f.tex_rgb.size());
+                        f.tex_w.push_back((uint32_t)ti->second.dim.x); f.tex_h.push_back((uint32_t)ti->second.dim.y);
+                        f.tex_rgb.insert(f.tex_rgb.end(), ti->second.rgb.begin(), ti->second.rgb.end());
+                    } else tid = known->second;
                 }
-                f.tri_tex.push_back(tid);
             }
+            f.tri_tex[o.tri_base + k] = tid;
         }
+        // pass 3 (parallel): node and triangle records
+        parallel_for(h.nodes.size(), 4096, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; i++) {
+                const Node& n = h.nodes[i];
+                const size_t g = (size_t)o.node_base + i;
+                for (int a = 0; a < 3; a++) { f.node_min[3 * g + a] = n.minBox[a]; f.node_max[3 * g + a] = n.maxBox[a]; }
+                const bool leaf = n.left < 0 && n.right < 0;
+                f.node_left[g] = leaf ? -1 : o.node_base + n.left;
+                f.node_right[g] = leaf ? -1 : o.node_base + n.right;
+                f.node_first[g] = leaf ? o.tri_base + (int32_t)n.first : -1;
+                f.node_count[g] = leaf ? (int32_t)n.count : 0;
+            }
+        });
+        parallel_for(tris.size(), 4096, [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; k++) {
+                const Triangle& t = tris[k];
+                const size_t g = (size_t)o.tri_base + k;
+                const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
+                for (int j = 0; j < 3; j++) for (int c = 0; c < 4; c++) f.tri_points[12 * g + 4 * j + c] = (*p[j])[c];
+                const vec2* tc[3] = { &t.colorOneCoordinate, &t.colorTwoCoordinate, &t.colorThreeCoordinate };
+                for (int j = 0; j < 3; j++) { f.tri_texcoord[6 * g + 2 * j] = tc[j]->x; f.tri_texcoord[6 * g + 2 * j + 1] = tc[j]->y; }
+                const vec3* nm[3] = { &t.normalOne, &t.normalTwo, &t.normalThree };
+                for (int j = 0; j < 3; j++) for (int c = 0; c < 3; c++) f.tri_normals[9 * g + 3 * j + c] = (*nm[j])[c];
+                f.tri_obj[g] = o.id;
+            }
+        });
     }
     return f;
 }
@@ -565,14 +699,30 @@ ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& li
     srt_scene_destroy(scene);
     if (rc != SRT_OK) throw std::runtime_error(std::string("srt_render: ") + srt_strerror(rc));
     ImageData out;
-    for (uint32_t x = 0; x < W; x++)                                     // reference emission order: x outer (:511-513)
-        for (uint32_t y = 0; y < H; y++) {
-            const uint8_t* c = &rgb8[((size_t)y * W + x) * 3];
-            if (c[0] | c[1] | c[2]) {
-                out.imagePoints.emplace_back((float)x, (float)y);
-                out.imageColors.emplace_back((float)c[0], (float)c[1], (float)c[2]);
+    // reference emission order: x outer, y inner (:511-513).  Count per column, then fill the slots in parallel.
+    std::vector<size_t> col(W + 1, 0);
+    parallel_for(W, 64, [&](size_t x0, size_t x1) {
+        for (size_t x = x0; x < x1; x++) {
+            size_t n = 0;
+            for (uint32_t y = 0; y < H; y++) { const uint8_t* c = &rgb8[((size_t)y * W + x) * 3]; n += (c[0] | c[1] | c[2]) != 0; }
+            col[x + 1] = n;
+        }
+    });
+    for (uint32_t x = 0; x < W; x++) col[x + 1] += col[x];
+    out.imagePoints.resize(col[W]); out.imageColors.resize(col[W]);
+    parallel_for(W, 64, [&](size_t x0, size_t x1) {
+        for (size_t x = x0; x < x1; x++) {
+            size_t k = col[x];
+            for (uint32_t y = 0; y < H; y++) {
+                const uint8_t* c = &rgb8[((size_t)y * W + x) * 3];
+                if (c[0] | c[1] | c[2]) {
+                    out.imagePoints[k] = vec2((float)x, (float)y);
+                    out.imageColors[k] = vec3((float)c[0], (float)c[1], (float)c[2]);
+                    k++;
+                }
             }
         }
+    });
     return out;
 }
 

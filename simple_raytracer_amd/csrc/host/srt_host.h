@@ -91,7 +91,11 @@ struct Texture { std::vector<unsigned char> rgb; ivec2 dim; };
 // Object.h:59-89
 class ObjectManager {
 public:
-    struct Hierarchy { std::vector<Node> nodes; std::vector<uint32_t> order; };   // nodes[0] = root, DFS pre-order
+    // nodes[0] = root, DFS pre-order; order = built (leaf, left-to-right) order as indices into the object's triangles AT
+    // BUILD TIME; triangles = those triangles, copied in that order.  The reference's Node keeps its triangles by value
+    // (Object.h:46-57), so what is rendered is the geometry as it was when createBoundingHierarchy ran, whatever
+    // transformTriangles / setTriangles do to the object afterwards; the copy keeps that behaviour.
+    struct Hierarchy { std::vector<Node> nodes; std::vector<uint32_t> order; std::vector<Triangle> triangles; };
     std::unordered_map<std::string, vec3> minBox, maxBox;
     std::unordered_map<std::string, vec3> objProperties;       // ambientStrength, specularStrength, shininess
     std::unordered_map<std::string, std::vector<Triangle>> objTriangles;

@@ -51,10 +51,10 @@ __device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long 
 // address would serialise for ~0.4 ms.  64 shards, 64 B apart, summed on the host.
 constexpr int HIT_SHARDS = 64;
 constexpr int CTR_HIT_BASE = 8;                  // counters[8 + 8*shard]
-__device__ __forceinline__ void count_hits(unsigned long long* counters, bool is_hit) {
+__device__ __forceinline__ void count_hits(unsigned long long* counters, bool is_hit, uint32_t tile_index) {
     const unsigned long long m = __ballot(is_hit);
     if ((threadIdx.x & 63) == 0 && m) {
-        const uint32_t shard = (blockIdx.y * gridDim.x + blockIdx.x) & (HIT_SHARDS - 1);
+        const uint32_t shard = tile_index & (HIT_SHARDS - 1);
         atomicAdd(counters + CTR_HIT_BASE + 8 * shard, (unsigned long long)__popcll(m));
     }
 }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
         }
         is_hit = id >= 0;
     }
-    count_hits(counters, is_hit);
+    count_hits(counters, is_hit, blockIdx.y * gridDim.x + blockIdx.x);
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
 
@@ -283,6 +283,14 @@ constexpr int LQ_WORDS = 2 * (64 + 64);     // (leaf, ray) pair queue of the nod
 // Diagnostic build only (python -m simple_raytracer_amd.build --diag -> libsrt_hip_diag.so, never shipped): per-wave
 // cycle stamps of the closest-hit phase, written where rgb_linear would go (8 x u64 per wave).
 #define SRT_STAMP(v) do { v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+// whole-tile record of the fused kernels: slot 5 = HW_ID | XCC_ID << 32, slots 6 / 7 = absolute start / end stamps
+__device__ __forceinline__ void diag_tile_record(float* rgb_linear, uint32_t bx, uint32_t by, uint32_t gx, unsigned long long k0, unsigned long long k1) {
+    if ((threadIdx.x & 63) == 0 && rgb_linear) {
+        unsigned long long* dgp = reinterpret_cast<unsigned long long*>(rgb_linear) + (((size_t)by * gx + bx) * 4 + (threadIdx.x >> 6)) * 8;
+        const unsigned long long hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        dgp[5] = hw | (xcc << 32); dgp[6] = k0; dgp[7] = k1;
+    }
+}
 #else
 #define SRT_STAMP(v) do { } while (0)
 #endif
@@ -294,12 +302,13 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                                                   unsigned long long* best, float4* dir,
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                  unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d) {
+                                                  unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d,
+                                                  const uint32_t bx, const uint32_t by, const uint32_t gx) {     // workgroup tile coordinates, tiles per row
     constexpr int P = 1 << (TWL + THL);           // rays per wavefront
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
-    const uint32_t tile_x = (blockIdx.x * 2 + (wave & 1)) << TWL, tile_r = (blockIdx.y * 2 + (wave >> 1)) << THL;
+    const uint32_t tile_x = (bx * 2 + (wave & 1)) << TWL, tile_r = (by * 2 + (wave >> 1)) << THL;
     const uint32_t px = tile_x + (lane & ((1u << TWL) - 1)), r = tile_r + ((lane >> TWL) & ((1u << THL) - 1));
     const bool live = lane < P && px < p.W && r < p.rows;
     const V3 o = mk(0.0f, 0.0f, 0.0f);
@@ -480,7 +489,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         unsigned long long c3; SRT_STAMP(c3);
         if (lane == 0 && rgb_linear) {
             unsigned long long* dgp = reinterpret_cast<unsigned long long*>(rgb_linear) +
-                                      (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+                                      (((size_t)by * gx + bx) * 4 + wave) * 8;
             dgp[0] = c3 - dg_t0; dgp[1] = dg_steps; dgp[2] = dg_batches; dgp[3] = dg_test; dgp[4] = dg_commit; dgp[5] = dg_tri;
             dgp[6] = dg_pop; dgp[7] = dg_load;
         }
@@ -512,7 +521,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         is_hit = id >= 0;
         out_id = id; out_t = t;
     }
-    count_hits(counters, is_hit);
+    count_hits(counters, is_hit, by * gx + bx);
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
 
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d);
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // =================================================================================================
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
             rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
         }
     }
-    count_hits(counters, is_hit);
+    count_hits(counters, is_hit, blockIdx.y * gridDim.x + blockIdx.x);
     if (COUNT) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
 }
 
@@ -665,7 +674,8 @@ struct ShadowLds {
 template <bool SEQ, int NQCAP, bool FILTER>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
                                              unsigned long long* bits, int32_t id, float t_hit, V3 d_hit,
-                                             unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
+                                             unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
+                                             const uint32_t bx, const uint32_t by, const uint32_t gx) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4* ray = L.ray;
     int2* selfr = L.selfr;
@@ -674,10 +684,10 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
     const uint32_t qx = wave & 1, qy = wave >> 1;
-    const uint32_t tile_x = blockIdx.x * 8 + qx * 4, tile_r = blockIdx.y * 8 + qy * 4;
+    const uint32_t tile_x = bx * 8 + qx * 4, tile_r = by * 8 + qy * 4;
     const uint32_t px = tile_x + (lane & 3), r = tile_r + ((lane >> 2) & 3);
     const bool live = lane < NQ_P && px < p.W && r < p.rows;
-    const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t tile_index = (size_t)by * gx + bx;
     unsigned long long n_node = 0, n_tri = 0;
     if (!live) id = -1;
     const uint32_t hm = (uint32_t)__ballot(id >= 0);
@@ -872,7 +882,7 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
-    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters);
+    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // =================================================================================================
@@ -892,10 +902,15 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     __shared__ unsigned long long bits[64];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
+    unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
+    SRT_STAMP(k0);
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d);
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x);
     __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters);
+    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
+#ifdef SRT_DIAG
+    SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
+#endif
 }
 
 // =================================================================================================
@@ -910,6 +925,9 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                     unsigned long long* __restrict__ counters_next) {
     if (counters_next) zero_next_counters(counters_next);
+#ifdef SRT_DIAG
+    rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
+#endif
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t px, r;
     if (!tile_pixel(p, px, r)) return;

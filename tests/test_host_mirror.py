@@ -94,6 +94,28 @@ def test_one_triangle_object_has_empty_left_leaf(host):
     assert np.all(f.node_min[1] == np.float32(3.4028235e38)) and np.all(f.node_max[1] == np.float32(-3.4028235e38))
 
 
+def test_hierarchy_keeps_the_geometry_of_build_time(host, oracle):
+    """The reference's Node holds its triangles by value (Object.h:46-57): what is rendered is the object as it was when
+    createBoundingHierarchy ran, whatever transformTriangles does afterwards.  Same here (and, where the compiled
+    reference is present, the same flat scene as its Node trees give)."""
+    T = host.Transformation
+    om = host.ObjectManager()
+    om.add_object("c", gu.load_mesh("cube")); om.transformTriangles("c", T.scaleObj(3.0, 4.0, 5.0)); om.build_bvh("c")
+    before = om.flatten()
+    om.transformTriangles("c", T.changeObjPosition(100.0, 0.0, 0.0))        # after the build: not rendered
+    after = om.flatten()
+    assert np.array_equal(bits(before.tri_points), bits(after.tri_points)) and np.array_equal(bits(before.node_min), bits(after.node_min))
+    om.build_bvh("c")
+    rebuilt = om.flatten()
+    assert not np.array_equal(bits(before.tri_points), bits(rebuilt.tri_points))
+    if oracle.ref_available():
+        r = oracle.RefScene()
+        r.add_object("c", gu.load_mesh("cube")); r.transform("c", T.scaleObj(3.0, 4.0, 5.0)); r.build_bvh("c")
+        r.transform("c", T.changeObjPosition(100.0, 0.0, 0.0))
+        rf = r.export()
+        assert np.array_equal(bits(rf.tri_points), bits(after.tri_points)) and np.array_equal(bits(rf.node_max), bits(after.node_max))
+
+
 def test_obj_loader_own_asset(host, tmp_path):
     """OBJ parsing: triangles, quads (shorter-diagonal split like tinyobjloader), negative indices, vt/vn."""
     p = tmp_path / "m.obj"
