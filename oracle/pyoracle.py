@@ -140,6 +140,8 @@ def ref_lib():
         L.ref_om_object_order.restype = C.c_uint32
         L.ref_om_tri_texture_name.restype = C.c_uint32
         L.ref_om_texture.restype = C.c_int
+        L.ref_stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]
+        L.ref_stbi_load.restype = C.c_int
         L.ref_render.restype = C.c_uint32
         L.ref_radians.restype = C.c_float
         L.ref_radians.argtypes = [C.c_float]
@@ -153,6 +155,17 @@ def ref_lib():
         L.ref_om_set_props.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
         _ref = L
     return _ref
+
+
+def ref_stbi_load(path):
+    """The reference's stbi_load(path, ..., 3) (Object.cpp:57): H x W x 3 uint8, or None."""
+    L = ref_lib()
+    w, h = C.c_int32(), C.c_int32()
+    if not L.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), None):
+        return None
+    rgb = np.empty((h.value, w.value, 3), np.uint8)
+    L.ref_stbi_load(path.encode(), C.byref(w), C.byref(h), _p(rgb, _u8p))
+    return rgb
 
 
 class RefMat:

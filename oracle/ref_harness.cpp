@@ -176,6 +176,20 @@ int ref_om_texture(void* om_, const char* texname, int32_t* w, int32_t* h, uint8
     return 1;
 }
 
+// The reference's image decoder as its loader calls it (Object.cpp:57: stbi_load(path, &w, &h, &ch, 3); the
+// implementation is compiled into the reference's Object.cpp).  rgb == null: dimensions only.  Returns 1 on success.
+extern "C" unsigned char* stbi_load(char const* filename, int* x, int* y, int* comp, int req_comp);
+extern "C" void stbi_image_free(void* p);
+int ref_stbi_load(const char* path, int32_t* w, int32_t* h, uint8_t* rgb) {
+    int x = 0, y = 0, ch = 0;
+    unsigned char* d = stbi_load(path, &x, &y, &ch, 3);
+    if (!d) return 0;
+    *w = x; *h = y;
+    if (rgb) std::memcpy(rgb, d, (size_t)x * y * 3);
+    stbi_image_free(d);
+    return 1;
+}
+
 // Object names in objTriangles iteration order (the order rayIntersection:409 visits them).
 uint32_t ref_om_object_order(void* om_, char* buf, uint32_t cap) {
     ObjectManager* om = (ObjectManager*)om_;

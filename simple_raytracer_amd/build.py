@@ -56,7 +56,7 @@ def build_host(force=False, verbose=False):
     """Host-side C++ mirror of the reference's scene interface (g++); links the HIP library for the
     drop-in sendRaysAndIntersectPointsColors."""
     hdir = os.path.join(CSRC, "host")
-    srcs = [os.path.join(hdir, "srt_host.cpp"), os.path.join(hdir, "srt_host_c.cpp")]
+    srcs = [os.path.join(hdir, "srt_host.cpp"), os.path.join(hdir, "srt_jpeg.cpp"), os.path.join(hdir, "srt_host_c.cpp")]
     deps = srcs + [os.path.join(hdir, "srt_host.h"), os.path.join(HERE, "..", "include", "srt.h"), LIB_HIP]
     if not force and not _stale(LIB_HOST, deps):
         return LIB_HOST

@@ -8,6 +8,7 @@
 #include "srt_host.h"
 
 #include <algorithm>
+#include <array>
 #include <thread>
 #include <atomic>
 #include <condition_variable>
@@ -210,8 +211,9 @@ mat4 Transformation::createViewMatrix(vec3 position, vec3 rotation) {
 
 // ------------------------------------------------------------------------------------------------
 // Texture decoding for the loader (the reference uses stbi_load(path, ..., 3), Object.cpp:57).
-// Supported here: PNG (8/16-bit, grey / RGB / palette / alpha, non-interlaced), binary PPM, 24/32-bit
-// BMP.  Anything else (JPEG) fails to load, which the reference also tolerates (:63-65).
+// Supported here: PNG (8/16-bit, grey / RGB / palette / alpha, non-interlaced), JPEG (baseline and progressive
+// Huffman, srt_jpeg.cpp), binary PPM, 24/32-bit BMP.  Anything else fails to load, which the reference also
+// tolerates (:63-65).
 // ------------------------------------------------------------------------------------------------
 static bool read_file(const std::string& path, std::vector<unsigned char>& out) {
     std::ifstream f(path, std::ios::binary);
@@ -305,17 +307,17 @@ static bool decode_bmp(const std::vector<unsigned char>& d, Texture& t) {
     return true;
 }
 
-static bool load_texture(const std::string& path, Texture& t) {
+bool load_texture(const std::string& path, Texture& t) {
     std::vector<unsigned char> d;
     if (!read_file(path, d)) return false;
-    return decode_png(d, t) || decode_ppm(d, t) || decode_bmp(d, t);
+    return decode_png(d, t) || decode_jpeg(d, t) || decode_ppm(d, t) || decode_bmp(d, t);
 }
 
 // ------------------------------------------------------------------------------------------------
 // loadObjFile, Object.cpp:25-170.  OBJ / MTL parsing restates what tinyobjloader's ObjReader does for
 // the statements the reference's assets use (v, vt, vn, f, usemtl, mtllib; newmtl, map_Kd):
 // triangulation on (quads split along the shorter diagonal, tiny_obj_loader.h:1562-1605; larger
-// polygons as a fan -- tinyobj uses earcut there), faces in file order.
+// polygons by earcut, :1618-1740), faces in file order.
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct ObjIndex { int v = -1, vt = -1, vn = -1; };
@@ -339,6 +341,203 @@ bool parse_triple(const char*& p, int nv, int nvt, int nvn, ObjIndex& o) {
     if (e != p) { fix_index((int)b, nvt, o.vt); p = e; }
     if (*p == '/') { p++; long c = std::strtol(p, &e, 10); if (e != p) { fix_index((int)c, nvn, o.vn); p = e; } }
     return true;
+}
+
+// Faces with more than four corners.  The reference builds tinyobjloader with TINYOBJLOADER_USE_MAPBOX_EARCUT
+// (simple_raytracer.cpp:16), so such a face is projected onto the plane of its Newell normal in f32
+// (tiny_obj_loader.h:1618-1701) and cut by mapbox earcut in f64 (mapbox/earcut.hpp).  Which triangles come out, and in
+// which order and rotation, is the algorithm's: ear slicing over a doubly linked ring that skips a vertex after every
+// cut, with the fall-backs filterPoints -> cureLocalIntersections -> splitEarcut.  Restated here for one ring without
+// holes (tinyobj never passes holes); the z-order hash earcut switches on above 80 vertices only narrows the set of
+// points an ear test visits and does not change its answer, so the plain test is used for every size.
+class Earcut {
+public:
+    std::vector<uint32_t> indices;
+    explicit Earcut(const std::vector<std::array<float, 2>>& ring) {
+        const size_t len = ring.size();
+        n_.reserve(len * 3 / 2 + 4);
+        double sum = 0;                                                   // winding (earcut.hpp linkedList)
+        for (size_t i = 0, j = len ? len - 1 : 0; i < len; j = i++) {
+            const double p10 = ring[i][0], p11 = ring[i][1], p20 = ring[j][0], p21 = ring[j][1];
+            sum += (p20 - p10) * (p11 + p21);
+        }
+        int last = -1;
+        if (sum > 0) for (size_t i = 0; i < len; i++) last = insert((uint32_t)i, ring[i][0], ring[i][1], last);
+        else         for (size_t i = len; i-- > 0;)   last = insert((uint32_t)i, ring[i][0], ring[i][1], last);
+        if (last >= 0 && equals(last, n_[last].next)) { remove(last); last = n_[last].next; }
+        if (last < 0 || n_[last].prev == n_[last].next) return;
+        slice(last, 0);
+    }
+
+private:
+    struct Node { uint32_t i; double x, y; int prev, next; };
+    std::vector<Node> n_;
+    int insert(uint32_t i, double x, double y, int last) {
+        const int p = (int)n_.size();
+        n_.push_back({ i, x, y, p, p });
+        if (last >= 0) { n_[p].next = n_[last].next; n_[p].prev = last; n_[n_[last].next].prev = p; n_[last].next = p; }
+        return p;
+    }
+    void remove(int p) { n_[n_[p].next].prev = n_[p].prev; n_[n_[p].prev].next = n_[p].next; }
+    double area(int p, int q, int r) const { return (n_[q].y - n_[p].y) * (n_[r].x - n_[q].x) - (n_[q].x - n_[p].x) * (n_[r].y - n_[q].y); }
+    bool equals(int a, int b) const { return n_[a].x == n_[b].x && n_[a].y == n_[b].y; }
+    static bool in_triangle(double ax, double ay, double bx, double by, double cx, double cy, double px, double py) {
+        return (cx - px) * (ay - py) - (ax - px) * (cy - py) >= 0 && (ax - px) * (by - py) - (bx - px) * (ay - py) >= 0 &&
+               (bx - px) * (cy - py) - (cx - px) * (by - py) >= 0;
+    }
+    bool is_ear(int ear) const {
+        const int a = n_[ear].prev, b = ear, c = n_[ear].next;
+        if (area(a, b, c) >= 0) return false;                             // reflex
+        for (int p = n_[c].next; p != a; p = n_[p].next)
+            if (in_triangle(n_[a].x, n_[a].y, n_[b].x, n_[b].y, n_[c].x, n_[c].y, n_[p].x, n_[p].y) && area(n_[p].prev, p, n_[p].next) >= 0) return false;
+        return true;
+    }
+    int filter(int start, int end = -1) {                                 // drop duplicate / collinear points
+        if (end < 0) end = start;
+        int p = start;
+        bool again;
+        do {
+            again = false;
+            if (equals(p, n_[p].next) || area(n_[p].prev, p, n_[p].next) == 0) {
+                remove(p);
+                p = end = n_[p].prev;
+                if (p == n_[p].next) break;
+                again = true;
+            } else p = n_[p].next;
+        } while (again || p != end);
+        return end;
+    }
+    void slice(int ear, int pass) {
+        int stop = ear;
+        while (n_[ear].prev != n_[ear].next) {
+            const int prev = n_[ear].prev, next = n_[ear].next;
+            if (is_ear(ear)) {
+                indices.push_back(n_[prev].i); indices.push_back(n_[ear].i); indices.push_back(n_[next].i);
+                remove(ear);
+                ear = n_[next].next; stop = n_[next].next;                // skipping a vertex gives fewer slivers
+                continue;
+            }
+            ear = next;
+            if (ear == stop) {                                            // went round without finding an ear
+                if (pass == 0) slice(filter(ear), 1);
+                else if (pass == 1) { ear = cure(filter(ear)); slice(ear, 2); }
+                else split(ear);
+                break;
+            }
+        }
+    }
+    static int sign(double v) { return (0.0 < v) - (v < 0.0); }
+    bool on_segment(int p, int q, int r) const {
+        return n_[q].x <= std::max(n_[p].x, n_[r].x) && n_[q].x >= std::min(n_[p].x, n_[r].x) &&
+               n_[q].y <= std::max(n_[p].y, n_[r].y) && n_[q].y >= std::min(n_[p].y, n_[r].y);
+    }
+    bool intersects(int p1, int q1, int p2, int q2) const {
+        const int o1 = sign(area(p1, q1, p2)), o2 = sign(area(p1, q1, q2)), o3 = sign(area(p2, q2, p1)), o4 = sign(area(p2, q2, q1));
+        if (o1 != o2 && o3 != o4) return true;
+        if (o1 == 0 && on_segment(p1, p2, q1)) return true;
+        if (o2 == 0 && on_segment(p1, q2, q1)) return true;
+        if (o3 == 0 && on_segment(p2, p1, q2)) return true;
+        if (o4 == 0 && on_segment(p2, q1, q2)) return true;
+        return false;
+    }
+    bool locally_inside(int a, int b) const {
+        return area(n_[a].prev, a, n_[a].next) < 0 ? area(a, b, n_[a].next) >= 0 && area(a, n_[a].prev, b) >= 0
+                                                   : area(a, b, n_[a].prev) < 0 || area(a, n_[a].next, b) < 0;
+    }
+    int cure(int start) {                                                 // small local self-intersections
+        int p = start;
+        do {
+            const int a = n_[p].prev, b = n_[n_[p].next].next;
+            if (!equals(a, b) && intersects(a, p, n_[p].next, b) && locally_inside(a, b) && locally_inside(b, a)) {
+                indices.push_back(n_[a].i); indices.push_back(n_[p].i); indices.push_back(n_[b].i);
+                remove(p); remove(n_[p].next);
+                p = start = b;
+            }
+            p = n_[p].next;
+        } while (p != start);
+        return filter(p);
+    }
+    bool intersects_polygon(int a, int b) const {
+        int p = a;
+        do {
+            const int q = n_[p].next;
+            if (n_[p].i != n_[a].i && n_[q].i != n_[a].i && n_[p].i != n_[b].i && n_[q].i != n_[b].i && intersects(p, q, a, b)) return true;
+            p = q;
+        } while (p != a);
+        return false;
+    }
+    bool middle_inside(int a, int b) const {
+        int p = a;
+        bool inside = false;
+        const double px = (n_[a].x + n_[b].x) / 2, py = (n_[a].y + n_[b].y) / 2;
+        do {
+            const int q = n_[p].next;
+            if (((n_[p].y > py) != (n_[q].y > py)) && n_[q].y != n_[p].y &&
+                (px < (n_[q].x - n_[p].x) * (py - n_[p].y) / (n_[q].y - n_[p].y) + n_[p].x)) inside = !inside;
+            p = q;
+        } while (p != a);
+        return inside;
+    }
+    bool valid_diagonal(int a, int b) const {
+        return n_[n_[a].next].i != n_[b].i && n_[n_[a].prev].i != n_[b].i && !intersects_polygon(a, b) &&
+               ((locally_inside(a, b) && locally_inside(b, a) && middle_inside(a, b) &&
+                 (area(n_[a].prev, a, n_[b].prev) != 0.0 || area(a, n_[b].prev, b) != 0.0)) ||
+                (equals(a, b) && area(n_[a].prev, a, n_[a].next) > 0 && area(n_[b].prev, b, n_[b].next) > 0));
+    }
+    int split_polygon(int a, int b) {
+        const int a2 = (int)n_.size(); n_.push_back({ n_[a].i, n_[a].x, n_[a].y, 0, 0 });
+        const int b2 = (int)n_.size(); n_.push_back({ n_[b].i, n_[b].x, n_[b].y, 0, 0 });
+        const int an = n_[a].next, bp = n_[b].prev;
+        n_[a].next = b; n_[b].prev = a;
+        n_[a2].next = an; n_[an].prev = a2;
+        n_[b2].next = a2; n_[a2].prev = b2;
+        n_[bp].next = b2; n_[b2].prev = bp;
+        return b2;
+    }
+    void split(int start) {                                               // last resort: cut along a valid diagonal
+        int a = start;
+        do {
+            int b = n_[n_[a].next].next;
+            while (b != n_[a].prev) {
+                if (n_[a].i != n_[b].i && valid_diagonal(a, b)) {
+                    int c = split_polygon(a, b);
+                    a = filter(a, n_[a].next);
+                    c = filter(c, n_[c].next);
+                    slice(a, 0); slice(c, 0);
+                    return;
+                }
+                b = n_[b].next;
+            }
+            a = n_[a].next;
+        } while (a != start);
+    }
+};
+
+// corner indices (into the face) of the triangles tinyobjloader makes of a face with more than four corners
+std::vector<uint32_t> triangulate_polygon(const std::vector<ObjIndex>& poly, const std::vector<float>& V) {
+    const size_t n = poly.size();
+    float nx = 0.f, ny = 0.f, nz = 0.f;                                    // Newell normal, f32 (:1624-1652)
+    for (size_t k = 0; k < n; k++) {
+        const float* p1 = &V[3 * (size_t)poly[k].v]; const float* p2 = &V[3 * (size_t)poly[(k + 1) % n].v];
+        const float ax = p1[0] - p2[0], ay = p1[1] - p2[1], az = p1[2] - p2[2];
+        const float bx = p1[0] + p2[0], by = p1[1] + p2[1], bz = p1[2] + p2[2];
+        nx += ay * bz; ny += az * bx; nz += ax * by;
+    }
+    const float len = std::sqrt(nx * nx + ny * ny + nz * nz);
+    if (len <= 0) return {};                                               // zero normal: the face is dropped (:1655-1657)
+    const float inv = -1.0f / len;
+    const float wx = nx * inv, wy = ny * inv, wz = nz * inv;
+    const float ax = std::fabs(wx) > 0.9999999f ? 0.f : 1.f, ay = std::fabs(wx) > 0.9999999f ? 1.f : 0.f, az = 0.f;
+    float vx = wy * az - wz * ay, vy = wz * ax - wx * az, vz = wx * ay - wy * ax;      // cross(axis_w, a)
+    const float il = 1.0f / std::sqrt(vx * vx + vy * vy + vz * vz);
+    vx *= il; vy *= il; vz *= il;
+    const float ux = wy * vz - wz * vy, uy = wz * vx - wx * vz, uz = wx * vy - wy * vx;  // cross(axis_w, axis_v)
+    std::vector<std::array<float, 2>> ring(n);
+    for (size_t k = 0; k < n; k++) {
+        const float* q = &V[3 * (size_t)poly[k].v];
+        ring[k] = { q[0] * ux + q[1] * uy + q[2] * uz, q[0] * vx + q[1] * vy + q[2] * vz };
+    }
+    return Earcut(ring).indices;
 }
 
 std::string dirname_of(const std::string& path) {
@@ -400,7 +599,11 @@ void ObjectManager::loadObjFile(const std::string& objFilename) {
                 float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z, sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
                 if (sqr02 < sqr13) { emit(0, 1, 2); emit(0, 2, 3); } else { emit(0, 1, 3); emit(1, 2, 3); }
             } else if (poly.size() > 4) {
-                for (size_t k = 1; k + 1 < poly.size(); k++) emit(0, (int)k, (int)k + 1);
+                bool ok = true;
+                for (auto& q : poly) ok &= (q.v >= 0 && 3 * (size_t)q.v + 2 < V.size());
+                if (!ok) continue;
+                const std::vector<uint32_t> tri = triangulate_polygon(poly, V);
+                for (size_t k = 0; k + 2 < tri.size(); k += 3) emit((int)tri[k], (int)tri[k + 1], (int)tri[k + 2]);
             }
         } else if (!std::strncmp(p, "usemtl", 6)) {
             std::string name = trim(p + 6);

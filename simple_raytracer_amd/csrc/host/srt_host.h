@@ -87,6 +87,10 @@ struct Node {
 };
 
 struct Texture { std::vector<unsigned char> rgb; ivec2 dim; };
+// baseline / progressive JPEG -> 8-bit RGB with stb_image's arithmetic (srt_jpeg.cpp)
+bool decode_jpeg(const std::vector<unsigned char>& file_bytes, Texture& out);
+// what stbi_load(path, &w, &h, &ch, 3) gives the reference (Object.cpp:57): PNG / JPEG / PPM / BMP by content
+bool load_texture(const std::string& path, Texture& out);
 
 // Object.h:59-89
 class ObjectManager {

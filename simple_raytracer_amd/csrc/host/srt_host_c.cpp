@@ -37,6 +37,16 @@ int srth_om_add_object(void* om_, const char* name, uint32_t n, const float* poi
     })
 }
 // Array-fed textured object: the state loadObjFile leaves for a textured mesh (Object.cpp:98-161)
+// decode an image file as the loader does; rgb == NULL: dimensions only.  Returns 0, or 1 if the file does not decode.
+int srth_decode_image(const char* path, int32_t* w, int32_t* h, uint8_t* rgb) {
+    try {
+        Texture t;
+        if (!load_texture(path, t)) return 1;
+        *w = t.dim.x; *h = t.dim.y;
+        if (rgb) std::memcpy(rgb, t.rgb.data(), t.rgb.size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 int srth_om_add_texture(void* om_, const char* texname, int32_t w, int32_t h, const uint8_t* rgb) {
     GUARD({
         ObjectManager* om = (ObjectManager*)om_;

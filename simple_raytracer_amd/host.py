@@ -33,6 +33,7 @@ def load():
             getattr(L, fn).argtypes = [C.c_void_p, C.c_char_p]
         L.srth_om_add_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p]
         L.srth_om_clone.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.srth_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]
         L.srth_om_add_texture.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _u8p]
         L.srth_om_add_textured_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p, _f32p, C.c_char_p]
         L.srth_om_set_color.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
@@ -219,6 +220,17 @@ class ObjectManager:
         if n < 0:
             raise HostError(self.L.srth_last_error().decode())
         return rgb, int(n)
+
+
+def decode_image(path):
+    """The texture loader's decode of an image file (PNG / JPEG / PPM / BMP): H x W x 3 uint8, or None."""
+    L = load()
+    w, h = C.c_int32(), C.c_int32()
+    if L.srth_decode_image(path.encode(), C.byref(w), C.byref(h), None):
+        return None
+    rgb = np.empty((h.value, w.value, 3), np.uint8)
+    L.srth_decode_image(path.encode(), C.byref(w), C.byref(h), _p(rgb, _u8p))
+    return rgb
 
 
 def write_bmp(path, rgb8):

@@ -10,6 +10,10 @@ Fixtures (all produced by the reference's own functions through oracle/ref_harne
   kat.npz                  leaf-function known-answer vectors (a4, a5, a8, a8b, a9, light staircase,
                            Transformation.h factories + glm inverse / mat*vec)
   meshes/<key>.npz         triangle meshes as the reference's loader (tinyobjloader) produced them
+  jpeg.npz                 small synthetic JPEG files (encoded here with Pillow) and the bytes the reference's
+                           stbi_load decodes them to; sha256 of the decode of the reference's own JPEG textures
+  polygons.npz             an OBJ of 5..120-corner faces and the triangles the reference's loader (tinyobjloader +
+                           mapbox earcut) makes of them
   scene_<name>.npz         recipe (JSON), the flat scene exported from the reference's Node* trees,
                            and per-resolution outputs: rgb8 of sendRaysAndIntersectPointsColors +
                            drawImage's background rule, closest-hit ids, and t / pre-tone-map /
@@ -303,8 +307,108 @@ def make_kat():
     print("kat.npz", os.path.getsize(os.path.join(HERE, "kat.npz")) // 1024, "KiB")
 
 
+def make_jpeg():
+    """Small synthetic JPEGs (encoded here with Pillow: our own inputs) and what the reference's stbi_load(path, ..., 3)
+    (Object.cpp:57) decodes them to: baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / grey / CMYK, restart intervals,
+    odd sizes down to one pixel, low and high quality.  Plus sha256 of the decode of the reference's own JPEG assets."""
+    import io
+    import tempfile
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([(x * 255) // max(w - 1, 1), (y * 255) // max(h - 1, 1), ((x + y) * 127) // max(w + h - 2, 1)], -1)
+        blobs = (rng.integers(0, 2, (h // 4 + 1, w // 4 + 1, 3)) * 255).repeat(4, 0).repeat(4, 1)[:h, :w]
+        return np.clip(base * 0.6 + blobs * 0.4 + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+    cases = [
+        ("base444", 48, 40, dict(quality=90, subsampling=0)),
+        ("base422", 50, 33, dict(quality=85, subsampling=1)),
+        ("base420", 57, 39, dict(quality=75, subsampling=2)),
+        ("base420_q20", 64, 48, dict(quality=20, subsampling=2)),
+        ("base444_q100", 31, 17, dict(quality=100, subsampling=0)),
+        ("prog444", 40, 40, dict(quality=88, subsampling=0, progressive=True)),
+        ("prog420", 61, 35, dict(quality=70, subsampling=2, progressive=True)),
+        ("prog422_q40", 33, 50, dict(quality=40, subsampling=1, progressive=True)),
+        ("rst444", 64, 40, dict(quality=90, subsampling=0, restart_marker_blocks=3)),
+        ("rst420", 70, 45, dict(quality=80, subsampling=2, restart_marker_rows=1)),
+        ("prog_rst420", 52, 52, dict(quality=80, subsampling=2, progressive=True, restart_marker_blocks=2)),
+        ("grey", 45, 29, dict(quality=85, mode="L")),
+        ("grey_prog", 23, 41, dict(quality=60, mode="L", progressive=True)),
+        ("cmyk", 36, 28, dict(quality=90, mode="CMYK")),
+        ("one_pixel", 1, 1, dict(quality=90, subsampling=2)),
+        ("one_column", 1, 19, dict(quality=90, subsampling=2)),
+        ("one_row", 21, 1, dict(quality=90, subsampling=1)),
+        ("optimized", 40, 30, dict(quality=85, subsampling=2, optimize=True)),
+    ]
+    d = {"names": np.array([c[0] for c in cases])}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, w, h, kw in cases:
+            kw = dict(kw)
+            mode = kw.pop("mode", "RGB")
+            im = Image.fromarray(picture(w, h), "RGB").convert(mode)
+            buf = io.BytesIO(); im.save(buf, "JPEG", **kw)
+            path = os.path.join(tmp, name + ".jpg")
+            open(path, "wb").write(buf.getvalue())
+            ref = po.ref_stbi_load(path)
+            assert ref is not None and ref.shape == (h, w, 3), name
+            d[f"{name}_file"] = np.frombuffer(buf.getvalue(), np.uint8)
+            d[f"{name}_rgb"] = ref
+    assets = ["obj/tree/10445_Oak_Tree_v1_diffuse.jpg", "obj/grass/10438_Circular_Grass_Patch_v1_Diffuse.jpg", "obj/horse/Horse_v01.jpg",
+              "obj/cat/Cat_diffuse.jpg", "obj/bird/12248_Bird_v1_diff.jpg", "obj/dog/13466_Canaan_Dog_diff.jpg", "obj/cat/Cat_bump.jpg"]
+    d["asset_names"] = np.array(assets)
+    d["asset_sha"] = np.array([sha(po.ref_stbi_load(os.path.join("/root/reference", a))) for a in assets])
+    np.savez_compressed(os.path.join(HERE, "jpeg.npz"), **d)
+    print("jpeg.npz", os.path.getsize(os.path.join(HERE, "jpeg.npz")) // 1024, "KiB")
+
+
+def make_polygons():
+    """An OBJ of faces with 5..120 corners (star-shaped, concave combs, collinear and duplicate corners, a bow-tie, a
+    figure-eight, tilted planes, slightly non-planar) and the triangles the reference's loader (tinyobjloader built with
+    mapbox earcut, simple_raytracer.cpp:15-16) makes of it."""
+    import tempfile
+    rng = np.random.default_rng(11)
+    verts, faces = [], []
+    def add(poly2d, frame=None, wobble=0.0):
+        poly2d = np.asarray(poly2d, np.float64)
+        if frame is None:
+            q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            frame = (q[:, 0], q[:, 1], rng.normal(size=3) * 3)
+        u, v, o = frame
+        base = len(verts)
+        for x, y in poly2d:
+            p = o + u * x + v * y + np.cross(u, v) * rng.normal() * wobble
+            verts.append(p)
+        faces.append(list(range(base + 1, base + 1 + len(poly2d))))
+    for n in (5, 6, 7, 8, 13, 32, 79, 80, 81, 120):                       # star-shaped, random radii (concave)
+        a = np.sort(rng.uniform(0, 2 * np.pi, n)); r = rng.uniform(0.4, 2.0, n)
+        add(np.stack([r * np.cos(a), r * np.sin(a)], 1))
+        add(np.stack([r * np.cos(a), r * np.sin(a)], 1)[::-1], wobble=0.01)   # other winding, slightly non-planar
+    comb = [(0, 0)] + [p for k in range(6) for p in ((k + 0.2, 3), (k + 0.5, 0.5), (k + 0.8, 3))] + [(6, 0)]
+    add(comb); add(comb, frame=(np.array([1., 0, 0]), np.array([0, 1., 0]), np.zeros(3)))
+    add([(0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 2), (1.5, 2), (0, 2), (0, 1)])              # collinear corners
+    add([(0, 0), (2, 0), (2, 0), (2, 2), (1, 1), (0, 2), (0, 2)])                                # duplicates
+    add([(0, 0), (2, 2), (2, 0), (0, 2), (1, 3)])                                                # bow-tie
+    add([(0, 0), (1, 1), (2, 0), (3, 1), (4, 0), (4, 2), (3, 1.2), (2, 2), (1, 1.2), (0, 2)])   # pinched
+    add([(0, 0), (4, 0), (4, 4), (0, 4), (0, 1), (3, 1), (3, 3), (1, 3), (1, 2), (2, 2), (2, 1.5), (0.5, 1.5), (0.5, 3.5), (3.5, 3.5), (3.5, 0.5), (0, 0.5)])  # spiral
+    add([(0, 0), (1, 0), (2, 0), (3, 0), (4, 0)])                                                # degenerate: zero area
+    add([(0, 0), (1, 0), (1, 1), (0, 1), (0.5, 0.5)], frame=(np.array([0, 0, 1.]), np.array([0, 1., 0]), np.array([5., 0, 0])))   # normal along x
+    text = "".join("v %.6f %.6f %.6f\n" % tuple(p) for p in verts) + "".join("f " + " ".join(map(str, f)) + "\n" for f in faces)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "polys.obj")
+        open(path, "w").write(text)
+        r = po.RefScene(); r.load_obj(path, cwd=tmp)
+        pts = r.points(path)
+    np.savez_compressed(os.path.join(HERE, "polygons.npz"), obj=np.frombuffer(text.encode(), np.uint8), points=pts)
+    print("polygons.npz", len(faces), "faces ->", len(pts), "triangles")
+
+
 def main():
     assert po.ref_available(), "build oracle/_ref first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] in ("jpeg", "polygons"):
+        (make_jpeg if sys.argv[1] == "jpeg" else make_polygons)()
+        return
+    make_jpeg()
+    make_polygons()
     meshes = {k: export_mesh(k) for k in REF_OBJ}
     make_kat()
     make_scene("cube", scenes.one_cube(M, 0.0), meshes, [(256, 256, 1, True), (37, 23, 1, True)])

@@ -132,6 +132,20 @@ def test_obj_loader_own_asset(host, tmp_path):
     assert np.array_equal(nrm[2, :3], [0, 0, 1]) and ht.sum() == 0
 
 
+def test_polygon_faces_are_cut_like_tinyobj_earcut(host, tmp_path):
+    """Faces with more than four corners: the reference's loader is tinyobjloader built with mapbox earcut
+    (simple_raytracer.cpp:15-16).  tests/golden/polygons.npz: 29 faces of 5..120 corners (concave, both windings,
+    collinear / duplicate corners, self-intersecting, degenerate, non-planar) and the 898 triangles the compiled reference
+    made of them: same triangles, same order, same corner rotation."""
+    z = np.load(os.path.join(gu.GOLDEN, "polygons.npz"))
+    p = tmp_path / "polys.obj"
+    p.write_bytes(z["obj"].tobytes())
+    om = host.ObjectManager(); om.loadObjFile(str(p))
+    got = om.points(str(p))
+    assert got.shape == z["points"].shape
+    assert np.array_equal(bits(got), bits(z["points"]))
+
+
 def test_obj_loader_matches_reference_loader(host, oracle):
     """Where the reference and its assets are present: same triangles as tinyobjloader + Object.cpp:70-167."""
     if not (oracle.ref_available() and os.path.exists("/root/reference/obj/stanford-bunny.obj")):
@@ -141,6 +155,19 @@ def test_obj_loader_matches_reference_loader(host, oracle):
         om = host.ObjectManager()
         om.loadObjFile(os.path.join("/root/reference", name))
         assert np.array_equal(bits(om.points(os.path.join("/root/reference", name))), bits(r.points(name))), name
+    # textured assets (JPEG / PNG diffuse maps with cwd-relative paths, house.obj has 5..32-corner faces): triangles,
+    # per-vertex integer texel coordinates (Object.cpp:113-119, from the decoded image's size), normals, texture bytes
+    old = os.getcwd()
+    os.chdir("/root/reference")
+    try:
+        for name in ("./obj/tree/tree.obj", "./obj/horse/horse.obj", "./obj/grass/grass.obj", "./obj/bird/bird.obj", "./obj/house/house.obj"):
+            r = oracle.RefScene(); r.load_obj(name)
+            om = host.ObjectManager(); om.loadObjFile(name)
+            assert np.array_equal(bits(om.points(name)), bits(r.points(name))), name
+            for a, b in zip(om.tri_attrs(name), r.tri_attrs(name)):
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), name
+    finally:
+        os.chdir(old)
 
 
 def test_texture_decoders_and_textured_loader(host, tmp_path, oracle):
@@ -164,6 +191,29 @@ def test_texture_decoders_and_textured_loader(host, tmp_path, oracle):
         r = oracle.RefScene(); r.load_obj(name, cwd=str(tmp_path))
         rtc, rcol, rht, _ = r.tri_attrs(name)
         assert np.array_equal(bits(tc), bits(rtc)) and np.array_equal(bits(col), bits(rcol)) and np.array_equal(ht, rht)
+
+
+def test_jpeg_decoder_gives_the_reference_loaders_bytes(host, tmp_path, oracle):
+    """The reference decodes textures with stbi_load(path, ..., 3) (Object.cpp:57) and most of its assets are JPEGs.
+    tests/golden/jpeg.npz: 18 small JPEG files (baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / grey / CMYK, restart
+    intervals, one-pixel edges) with the bytes the compiled reference decoded them to: the loader's decoder must give
+    exactly those.  Where the reference's assets are present, its seven 1024x1024 textures too (sha256 + live)."""
+    import hashlib
+    z = np.load(os.path.join(gu.GOLDEN, "jpeg.npz"))
+    for name in z["names"]:
+        p = tmp_path / f"{name}.jpg"
+        p.write_bytes(z[f"{name}_file"].tobytes())
+        got = host.decode_image(str(p))
+        assert got is not None, name
+        assert got.shape == z[f"{name}_rgb"].shape and np.array_equal(got, z[f"{name}_rgb"]), name
+    (tmp_path / "bad.jpg").write_bytes(z["base444_file"].tobytes()[:100])
+    assert host.decode_image(str(tmp_path / "bad.jpg")) is None
+    if os.path.exists("/root/reference/obj/tree/10445_Oak_Tree_v1_diffuse.jpg"):
+        for a, want in zip(z["asset_names"], z["asset_sha"]):
+            got = host.decode_image(os.path.join("/root/reference", str(a)))
+            assert hashlib.sha256(got.tobytes()).hexdigest() == str(want), a
+            if oracle.ref_available():
+                assert np.array_equal(got, oracle.ref_stbi_load(os.path.join("/root/reference", str(a)))), a
 
 
 def test_integration_adapter_compiles_against_the_reference(tmp_path):
