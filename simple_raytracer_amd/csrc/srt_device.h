@@ -91,11 +91,17 @@ __device__ __forceinline__ bool ray_aabb_nb(V3 o, V3 d, float mnx, float mny, fl
 
 // Filtered form of the same predicate.  The six quotients are approximated as (box - o) * rcp(d) -- the
 // subtraction is the reference's own, so only the division is approximate (<= ~3 ulp against the
-// reference's correctly rounded quotient).  Every comparison of the reference is then decided with a
-// margin that covers the error of both operands (min / max selection is 1-Lipschitz, so the folded
-// interval ends keep a relative error of a few ulp of their own magnitude); if any comparison falls
-// inside its margin, or anything is not finite, `ambiguous` is set and the caller must evaluate
-// ray_aabb_nb instead.  When `ambiguous` is false the returned bool equals the reference's.
+// reference's correctly rounded quotient).  For FINITE quotients the reference's comparison chain is the
+// classic slab test: after the per-axis swaps, "not (maxX < minY or maxY < minX)" is lo <= hi with
+// lo = max(minX, minY), hi = min(maxX, maxY), and "not (lo > maxZ or minZ > hi)" adds lo <= maxZ and
+// minZ <= hi, so the box passes iff  tnear = max3(minX, minY, minZ) <= tfar = min3(maxX, maxY, maxZ).
+// min / max selection is 1-Lipschitz, so tnear and tfar carry the quotients' relative error and ONE
+// comparison with a margin that covers both decides; if it falls inside the margin `ambiguous` is set and
+// the caller must evaluate ray_aabb_nb (the reference's comparisons one by one).  Non-finite quotients
+// (d = 0, 0 * inf, the FLT_MAX boxes of empty leaves) end up as an infinity or NaN in tnear / tfar -- a
+// NaN quotient always has an infinite partner from the same rcp, and v_min / v_max return the other
+// operand -- which makes the margin infinite or the difference NaN: ambiguous as well.
+// When `ambiguous` is false the returned bool equals the reference's.
 struct RayRcp { float x, y, z; };
 __device__ __forceinline__ RayRcp ray_rcp(V3 d) {
     RayRcp r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y); r.z = __builtin_amdgcn_rcpf(d.z); return r;
@@ -106,34 +112,12 @@ __device__ __forceinline__ bool ray_aabb_filtered(V3 o, RayRcp rc, float mnx, fl
     const float x0 = (mnx - o.x) * rc.x, x1 = (mxx - o.x) * rc.x;
     const float y0 = (mny - o.y) * rc.y, y1 = (mxy - o.y) * rc.y;
     const float z0 = (mnz - o.z) * rc.z, z1 = (mxz - o.z) * rc.z;
-    float minX = __builtin_fminf(x0, x1), maxX = __builtin_fmaxf(x0, x1);
-    const float minY = __builtin_fminf(y0, y1), maxY = __builtin_fmaxf(y0, y1);
-    const float minZ = __builtin_fminf(z0, z1), maxZ = __builtin_fmaxf(z0, z1);
-    // anything non-finite (0 * inf, x / 0, overflow) or absurdly large makes the sum NaN / inf / huge -> ambiguous
-    const float big = ((__builtin_fabsf(x0) + __builtin_fabsf(x1)) + (__builtin_fabsf(y0) + __builtin_fabsf(y1))) +
-                      (__builtin_fabsf(z0) + __builtin_fabsf(z1));
-    bool amb = !(big < 1.0e30f);
-    // decide (a < b): certain when |a - b| exceeds the margin
-    #define SRT_LT(a, b, res)                                                            \
-        {                                                                                \
-            const float m_ = __builtin_fmaf(E, __builtin_fabsf(a) + __builtin_fabsf(b), TINY);   \
-            const float df_ = (b) - (a);                                                 \
-            res = df_ > 0.0f;                                                            \
-            amb |= !(__builtin_fabsf(df_) > m_);                                         \
-        }
-    bool r1, r2, r3, r4;
-    SRT_LT(maxX, minY, r1);            // maxXT < minYT
-    SRT_LT(maxY, minX, r2);            // maxYT < minXT
-    const bool rej_xy = r1 | r2;
-    minX = __builtin_fmaxf(minX, minY);    // if (minYT > minXT) minXT = minYT
-    maxX = __builtin_fminf(maxX, maxY);    // if (maxYT < maxXT) maxXT = maxYT
-    SRT_LT(maxZ, minX, r3);            // minXT > maxZT
-    SRT_LT(maxX, minZ, r4);            // minZT > maxXT
-    #undef SRT_LT
-    // the z comparisons only matter when the xy test did not reject; their ambiguity is ignored otherwise
-    // (conservative: an ambiguous z comparison of an xy-rejected box still falls back, which is only slower)
-    ambiguous = amb;
-    return !(rej_xy | r3 | r4);
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    const float m = __builtin_fmaf(E, __builtin_fabsf(tnear) + __builtin_fabsf(tfar), TINY);
+    const float df = tfar - tnear;
+    ambiguous = !(__builtin_fabsf(df) > m);            // also true when df is NaN or m is inf
+    return df > 0.0f;
 }
 
 // ---- a5: rayTriangleIntersection, simple_raytracer.cpp:42-75 (Moller-Trumbore) ------------------
