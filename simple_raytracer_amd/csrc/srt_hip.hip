@@ -85,6 +85,17 @@ static DevTri derive_triangle(const float* p) {
     return t;
 }
 
+// tvec = o - P1 with o = 0 (:53) and qvec = cross(tvec, e1) (:58, glm::cross) for rays from the origin
+static DevTriO derive_triangle_origin(const DevTri& t) {
+    DevTriO r;
+    r.tx = 0.0f - t.p1x; r.ty = 0.0f - t.p1y; r.tz = 0.0f - t.p1z;
+    r.e1x = t.e1x; r.e1y = t.e1y; r.e1z = t.e1z; r.e2x = t.e2x; r.e2y = t.e2y; r.e2z = t.e2z;
+    r.qx = r.ty * t.e1z - t.e1y * r.tz;
+    r.qy = r.tz * t.e1x - t.e1z * r.tx;
+    r.qz = r.tx * t.e1y - t.e1x * r.ty;
+    return r;
+}
+
 extern "C" {
 
 uint32_t srt_abi_version(void) { return SRT_ABI_VERSION; }
@@ -244,7 +255,8 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     int rc = build_device_records(d, nodes, ranges);
     if (rc != SRT_OK) return rc;
     std::vector<DevTri> tris(d->n_tris);
-    for (uint32_t i = 0; i < d->n_tris; i++) tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i);
+    std::vector<DevTriO> tris_o(d->n_tris);
+    for (uint32_t i = 0; i < d->n_tris; i++) { tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i); tris_o[i] = derive_triangle_origin(tris[i]); }
 
     HIP_TRY(hipSetDevice(device));
     srt_scene* s = new (std::nothrow) srt_scene();
@@ -253,6 +265,7 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     #define UP(expr) do { rc = (expr); if (rc != SRT_OK) { srt_scene_destroy(s); return rc; } } while (0)
     UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
     UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
+    UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
     UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
     UP(upload(s, ranges.data(), ranges.size(), &s->dev.obj_range));
     UP(upload(s, d->obj_color, (size_t)d->n_objects * 3, &s->dev.obj_color));

@@ -13,6 +13,7 @@ using namespace srt;
 struct DevScene {
     const DevNode* nodes;
     const DevTri* tris;
+    const DevTriO* tris_o;        // the same triangles as rays from the origin test them (closest-hit phase)
     const int32_t* tri_obj;
     const int32_t* tri_tex;       // may be null (no textures)
     const float* tri_tc;          // n_tris x 6, may be null
@@ -347,16 +348,16 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             uint32_t bi = 0;
             // two triangles per iteration: their Moller-Trumbore chains are independent and interleave (the chain of a
             // single test is ~100 dependent VALU ops); the update order keeps the first minimum
-            const float4* tp = tris4 + (size_t)first * 3;
+            const float4* tp = reinterpret_cast<const float4*>(s.tris_o) + (size_t)first * 3;
             for (uint32_t k = 0; k < cnt; k += 2) {
                 const bool two = k + 1 < cnt;
-                const float4 a0 = tp[0], a1 = tp[1]; const float az = reinterpret_cast<const float*>(tp + 2)[0];
+                const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
                 const float4* tq_ = two ? tp + 3 : tp;
-                const float4 b0 = tq_[0], b1 = tq_[1]; const float bz = reinterpret_cast<const float*>(tq_ + 2)[0];
+                const float4 b0 = tq_[0], b1 = tq_[1], b2 = tq_[2];
                 tp += 6;
                 if (COUNT) n_tri += two ? 2 : 1;
-                const float ta = ray_triangle(o, d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, az));
-                const float tb_ = ray_triangle(o, d, mk(b0.x, b0.y, b0.z), mk(b0.w, b1.x, b1.y), mk(b1.z, b1.w, bz));
+                const float ta = ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
+                const float tb_ = ray_triangle_origin(d, mk(b0.x, b0.y, b0.z), mk(b0.w, b1.x, b1.y), mk(b1.z, b1.w, b2.x), mk(b2.y, b2.z, b2.w));
                 // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
                 if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
                 if (two && tb_ != SRT_NEG_INF && tb_ < bt) { bt = tb_; bi = first + k + 1; }
@@ -505,11 +506,15 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         float t = __builtin_inff();
         if (key != ~0ull) {
             id = (int32_t)(uint32_t)key;
-            // the winner's t with its own bits (incl. the sign of a zero): same function, same inputs
-            const size_t ti = (size_t)id * 3;
-            const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
-            const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
-            t = ray_triangle(o, dmine, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+            // the key carries the winner's t bit for bit, except that -0.0 was merged as +0.0 (they tie, :429): only a
+            // zero is evaluated again, to get its sign (same function, same inputs)
+            t = __uint_as_float((uint32_t)(key >> 32));
+            if (t == 0.0f) {
+                const size_t ti = (size_t)id * 3;
+                const float4 t0 = tris4[ti], t1 = tris4[ti + 1];
+                const float e2z = reinterpret_cast<const float*>(tris4 + ti + 2)[0];
+                t = ray_triangle(o, dmine, mk(t0.x, t0.y, t0.z), mk(t0.w, t1.x, t1.y), mk(t1.z, t1.w, e2z));
+            }
         }
         const size_t pix = (size_t)r * p.W + px;
         hit_id[pix] = id;
