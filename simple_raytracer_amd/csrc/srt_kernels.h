@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
 // rays of a step share their origin.  shadowIntersection:321-342: origin d*t, direction L - d*t
 // (unnormalised, no epsilon); any candidate of ANOTHER object with Moller-Trumbore != -inf (NaN included)
 // shadows.  A hit raises the ray's flag; queued pairs of a flagged ray are dropped when popped.
-// Result: per 8x8 tile and light sample one 64-bit word, bit = y*8 + x inside the tile.
+// Result: per 8x8 tile and light sample one 64-bit word of four 16-bit fields, field = quadrant (wave), bit = y*4 + x inside it.
 // SEQ = true is the counting build: per-ray sequential pre-order walk with exit at the first hit, whose
 // slab / triangle test counts are the algorithmic counts the CPU oracle mirrors.
 // =================================================================================================
@@ -672,13 +672,15 @@ struct ShadowLds {
     float2 pdir[NQ_P];             // per hit rank: primary ray direction x, y
     int2 selfr[NQ_P];              // per ray slot: node range of the hit object
     uint32_t flag[NQ_P];
+    uint32_t mask[64];             // per light sample of the current group: shadowed pixels of this wave's 4x4 quadrant
 };
 
-// Runs per wavefront; `id` / `t_hit` are the hit id and t of this lane's pixel (lanes < 16; -1 = miss).  `bits`
-// is the workgroup's 64-entry word array; ALL four waves of the workgroup must call this (it synchronises).
+// Runs per wavefront, with no workgroup-level synchronisation: `id` / `t_hit` are the hit id and t of this lane's pixel
+// (lanes < 16; -1 = miss).  The wave writes its own 16-bit field of the tile's word (field = quadrant, bit = pixel lane
+// y * 4 + x inside the quadrant), so a wave that is done leaves the CU without waiting for its three neighbours.
 template <bool SEQ, int NQCAP, bool FILTER>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
-                                             unsigned long long* bits, int32_t id, float t_hit, V3 d_hit,
+                                             int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
                                              const uint32_t bx, const uint32_t by, const uint32_t gx) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -747,8 +749,8 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     const uint32_t n_obj = s.n_objects;
     for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {               // light samples in groups of 64
         const uint32_t Lg = (p.n_lights - l0) < 64u ? (p.n_lights - l0) : 64u;
-        if (threadIdx.x < 64) bits[threadIdx.x] = 0ull;
-        __syncthreads();
+        L.mask[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
         const uint32_t n_items = nh * Lg;
         for (uint32_t base = 0; base < n_items; base += NQ_P) {      // 16 rays per round
             const uint32_t item = base + lane;
@@ -865,11 +867,11 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                 shadowed = valid && flag[lane] != 0u;
                 __builtin_amdgcn_wave_barrier();
             }
-            if (shadowed && valid) atomicOr(&bits[lg], 1ull << ((qy * 4 + (pl >> 2)) * 8 + qx * 4 + (pl & 3)));
+            if (shadowed && valid) atomicOr(&L.mask[lg], 1u << pl);
         }
-        __syncthreads();
-        if (threadIdx.x < Lg) shadow_bits[tile_index * p.n_lights + l0 + threadIdx.x] = bits[threadIdx.x];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        if (lane < Lg) reinterpret_cast<uint16_t*>(shadow_bits)[(tile_index * p.n_lights + l0 + lane) * 4 + wave] = (uint16_t)L.mask[lane];
+        __builtin_amdgcn_wave_barrier();
     }
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
 }
@@ -881,13 +883,12 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ ShadowLds lds_all[4];
-    __shared__ unsigned long long bits[64];          // per light of the current group: shadowed pixels of the 8x8 tile
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
-    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
+    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // =================================================================================================
@@ -904,7 +905,6 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     __shared__ unsigned long long best_all[4][NQ_P];
     __shared__ float4 dir_all[4][NQ_P];
     __shared__ ShadowLds lds_all[4];
-    __shared__ unsigned long long bits[64];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x);
     __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], bits, id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
+    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
 #ifdef SRT_DIAG
     SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
 #endif
@@ -974,9 +974,11 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
     }
     V3 sum = mk(0.0f, 0.0f, 0.0f);
     const unsigned long long* sb = shadow_bits + tile_index * p.n_lights;
+    // the tile's word: one 16-bit field per 4x4 quadrant (the wave that traced it), bit = y * 4 + x inside the quadrant
+    const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-        const bool shadowed = (sb[l] >> lane) & 1ull;
+        const bool shadowed = (sb[l] >> sbit) & 1ull;
         V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
         if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
         sum = sum + c;                                                                          // :370
