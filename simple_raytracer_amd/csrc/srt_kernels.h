@@ -304,9 +304,10 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d,
-                                                  const uint32_t bx, const uint32_t by, const uint32_t gx) {     // workgroup tile coordinates, tiles per row
+                                                  const uint32_t bx, const uint32_t by, const uint32_t gx,      // workgroup tile coordinates, tiles per row
+                                                  const uint32_t wave) {                                        // quadrant of the tile this wave owns
     constexpr int P = 1 << (TWL + THL);           // rays per wavefront
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
     const uint32_t tile_x = (bx * 2 + (wave & 1)) << TWL, tile_r = (by * 2 + (wave >> 1)) << THL;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x);
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
 }
 
 // =================================================================================================
@@ -682,8 +683,8 @@ template <bool SEQ, int NQCAP, bool FILTER>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
                                              int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
-                                             const uint32_t bx, const uint32_t by, const uint32_t gx) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                             const uint32_t bx, const uint32_t by, const uint32_t gx, const uint32_t wave) {
+    const uint32_t lane = threadIdx.x & 63;
     float4* ray = L.ray;
     int2* selfr = L.selfr;
     uint32_t* flag = L.flag;
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
-    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
+    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
 }
 
 // =================================================================================================
@@ -910,9 +911,9 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
     SRT_STAMP(k0);
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x);
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
     __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x);
+    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
 #ifdef SRT_DIAG
     SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
 #endif
