@@ -436,9 +436,11 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
         default:                                           // shipped: closest hit + shadow rays fused in one launch
             if (fused) {
-                if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
-                else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
-                else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (variant == 17 || (variant == 0 && p->n_lights >= 8))      // many light samples: 64 shadow rays in flight per wave
+                                        hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }

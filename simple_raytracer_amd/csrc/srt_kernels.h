@@ -667,20 +667,21 @@ __global__ __launch_bounds__(256) void k_shade(DevScene s, DevParams p, const in
 // slab / triangle test counts are the algorithmic counts the CPU oracle mirrors.
 // =================================================================================================
 // Per-wave LDS of the shadow phase (beside the two queues)
+template <int RS>                  // RS = shadow rays in flight per round: 16, or 64 when there are many light samples
 struct ShadowLds {
-    float4 ray[2 * NQ_P];          // per ray slot: origin, direction
+    float4 ray[2 * RS];            // per ray slot: origin, direction
     float4 pixd[NQ_P];             // per hit rank: t, pixel lane, own object's node range
     float2 pdir[NQ_P];             // per hit rank: primary ray direction x, y
-    int2 selfr[NQ_P];              // per ray slot: node range of the hit object
-    uint32_t flag[NQ_P];
+    int2 selfr[RS];                // per ray slot: node range of the hit object
+    uint32_t flag[RS];
     uint32_t mask[64];             // per light sample of the current group: shadowed pixels of this wave's 4x4 quadrant
 };
 
 // Runs per wavefront, with no workgroup-level synchronisation: `id` / `t_hit` are the hit id and t of this lane's pixel
 // (lanes < 16; -1 = miss).  The wave writes its own 16-bit field of the tile's word (field = quadrant, bit = pixel lane
 // y * 4 + x inside the quadrant), so a wave that is done leaves the CU without waiting for its three neighbours.
-template <bool SEQ, int NQCAP, bool FILTER>
-__device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds& L,
+template <bool SEQ, int NQCAP, bool FILTER, int RS>
+__device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds<RS>& L,
                                              int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
                                              const uint32_t bx, const uint32_t by, const uint32_t gx, const uint32_t wave) {
@@ -716,7 +717,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
             const uint32_t info = tq[2 * (tqn + lane)], rs = tq[2 * (tqn + lane) + 1];
             if (!flag[rs]) {
                 const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
-                const float4 ro4 = ray[rs], rd4 = ray[NQ_P + rs];
+                const float4 ro4 = ray[rs], rd4 = ray[RS + rs];
                 const V3 ro = mk(ro4.x, ro4.y, ro4.z), rd = mk(rd4.x, rd4.y, rd4.z);
                 const float4* tp = tris4 + (size_t)first * 3;
                 float4 t0 = tp[0], t1 = tp[1];
@@ -746,16 +747,16 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         }
     };
 
-    constexpr uint32_t OBJ_G = (NQCAP / 32) < 16 ? (NQCAP / 32) : 16;
+    constexpr uint32_t OBJ_G = (NQCAP / (2 * RS)) < 16 ? (NQCAP / (2 * RS)) : 16;     // RS * OBJ_G <= NQCAP / 2
     const uint32_t n_obj = s.n_objects;
     for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {               // light samples in groups of 64
         const uint32_t Lg = (p.n_lights - l0) < 64u ? (p.n_lights - l0) : 64u;
         L.mask[lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_items = nh * Lg;
-        for (uint32_t base = 0; base < n_items; base += NQ_P) {      // 16 rays per round
+        for (uint32_t base = 0; base < n_items; base += RS) {        // RS rays per round
             const uint32_t item = base + lane;
-            const bool valid = lane < NQ_P && item < n_items;
+            const bool valid = lane < RS && item < n_items;
             uint32_t pl = 0, lg = 0;
             V3 so = mk(0.f, 0.f, 0.f), sd = mk(0.f, 0.f, 1.f);
             int2 self = make_int2(-1, -1);
@@ -776,20 +777,20 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
             if (SEQ) {
                 if (valid) shadowed = any_hit_range<true>(s, self, so, sd, n_node, n_tri);
             } else {
-                if (lane < NQ_P) {
+                if (lane < RS) {
                     ray[lane] = make_float4(so.x, so.y, so.z, 0.f);
-                    ray[NQ_P + lane] = make_float4(sd.x, sd.y, sd.z, 0.f);
+                    ray[RS + lane] = make_float4(sd.x, sd.y, sd.z, 0.f);
                     selfr[lane] = self;
                     flag[lane] = valid ? 0u : 1u;
                 }
-                const uint32_t validm = (uint32_t)__ballot(valid);
+                const unsigned long long validm = __ballot(valid);
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t obj0 = 0; obj0 < n_obj; obj0 += OBJ_G) {
                     const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
-                    for (uint32_t kb = 0; kb < NQ_P * g; kb += 64) {
+                    for (uint32_t kb = 0; kb < RS * g; kb += 64) {
                         const uint32_t k = kb + lane;
-                        const uint32_t rs = k & (NQ_P - 1), ob = k >> 4;
-                        bool ok = k < NQ_P * g && ((validm >> rs) & 1u);
+                        const uint32_t rs = k & (RS - 1), ob = k / RS;
+                        bool ok = k < RS * g && ((validm >> rs) & 1ull);
                         int32_t root = 0;
                         if (ok) { root = s.obj_range[obj0 + ob].x; ok = root != selfr[rs].x; }   // never the hit object's own tree (:331)
                         const unsigned long long m = __ballot(ok);
@@ -809,7 +810,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                             rs = e & 63u; node = (int32_t)(e >> 6);
                             if (!flag[rs]) {                          // already shadowed rays drop their queued pairs
                                 const float4 a = nodes4[2 * (size_t)node], b = nodes4[2 * (size_t)node + 1];
-                                const float4 o4 = ray[rs], d4 = ray[NQ_P + rs];
+                                const float4 o4 = ray[rs], d4 = ray[RS + rs];
                                 ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
                                 skip = __float_as_int(b.z); info = __float_as_int(b.w);
                                 bool pass;
@@ -883,13 +884,13 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
                                                    unsigned long long* __restrict__ counters) {
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
-    __shared__ ShadowLds lds_all[4];
+    __shared__ ShadowLds<16> lds_all[4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
-    shadow_phase<SEQ, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
+    shadow_phase<SEQ, NQCAP, FILTER, 16>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
 }
 
 // =================================================================================================
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, cons
 // tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
 // a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
 // =================================================================================================
-template <bool COUNT, int NQCAP, bool FILTER, int MINW>
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][NQ_P];
     __shared__ float4 dir_all[4][NQ_P];
-    __shared__ ShadowLds lds_all[4];
+    __shared__ ShadowLds<RS> lds_all[4];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
     __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
+    shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
 #ifdef SRT_DIAG
     SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
 #endif
