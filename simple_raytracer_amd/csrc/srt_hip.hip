@@ -432,6 +432,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
             break;
         case 3: LAUNCH_NQ(160, 2, 2, false); break;      // tiny node queue: exercises the stackless overflow path
         case 4: LAUNCH_NQ(512, 2, 2, false); break;      // shipped geometry with exact divides only
+        case 6: LAUNCH_NQ(160, 2, 2, true); break;       // tiny node queue + filtered slab test: the overflow walk as shipped
         case 5: LAUNCH_NQ(1024, 3, 2, false); break;     // 8x4 pixels per wave, 1024-entry queue (tile-size experiment)
         case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
         default:                                           // shipped: closest hit + shadow rays fused in one launch
@@ -452,6 +453,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         if (p->n_lights && !fused) {
             if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());

@@ -126,7 +126,7 @@ def test_deep_soup_rows_match_oracle(srt, oracle):
     p = abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK, **kw)
     c = oracle.render(flat, p)
     assert c["hit_id"].shape[0] == 8 and (c["hit_id"] >= 0).mean() > 0.1
-    for variant in (0, 3):
+    for variant in (0, 3, 6):
         o = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8), **kw))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
@@ -190,7 +190,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -228,7 +228,7 @@ def test_big_leaves_and_signed_zero_t(srt, oracle):
                          obj_root=[0], tri_points=pts, tri_obj=np.zeros(n, np.int32),
                          obj_color=[[0.8, 0.6, 0.2]], obj_material=[[0.2, 0.5, 15.0]])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 1, 2, 3, 4, 5, 10):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 10):
         p = abi.make_params(96, 64, [[100.0, -200.0, 50.0]], flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
@@ -358,7 +358,7 @@ def test_many_objects_empty_objects_and_no_lights(srt, oracle):
     flat = host.build_flat_scene(recipe, meshes)
     assert flat.n_objects == 40 and 0 in list(flat.node_count[flat.node_left < 0])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 3, 10):
+    for variant in (0, 3, 6, 10):
         p = abi.make_params(203, 117, abi.light_staircase(recipe.light, 2), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
@@ -451,7 +451,7 @@ def test_adversarial_scenes_match_oracle(srt, oracle, seed):
     p = abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK)
     c = oracle.render(flat, p)
     assert (c["hit_id"] >= 0).sum() > 200
-    for variant in (0, 4, 3):
+    for variant in (0, 4, 3, 6):
         o = ds.render(abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8)))
         assert np.array_equal(o["hit_id"], c["hit_id"]), f"variant {variant}: {int((o['hit_id'] != c['hit_id']).sum())} hit ids differ"
         assert np.array_equal(bits(o["t"]), bits(c["t"]))
