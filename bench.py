@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=1, help="EXTENSION (not in the reference): n^2 sub-pixel samples per pixel, one launch pair each "
+                                                       "(BASELINE.json configs[4] names 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the frames of a step are spread over (each with its own scene handle and buffers).  Default: 1 "
@@ -97,7 +99,7 @@ def main():
     from simple_raytracer_amd import tiling
     emu = [int(x) for x in args.emulate_split.split("/")] if args.emulate_split else None
     split_rank, split_world = (emu if emu else (rank, world))
-    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8)
+    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8, spp=args.spp)
     rows = scene.rows(p)
     dev = torch.device("cuda", local_rank)
     hit = torch.empty((S, rows, W), dtype=torch.int32, device=dev)
@@ -135,7 +137,7 @@ def main():
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
     graphs = None
     if not args.no_graph and B % 2 == 0:
-        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING)
+        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING, spp=args.spp)
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
             graphs = []
@@ -193,7 +195,7 @@ def main():
 
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
-                         flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8))
+                         flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8), spp=args.spp)
     scene.render_device(pc, stream=stream, hit_id=hit[0].data_ptr(), t=tbuf[0].data_ptr(), rgb_linear=lin[0].data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
@@ -209,6 +211,10 @@ def main():
     value = rays_total * B / (dt / args.steps) / 1e6
 
     if rank == 0:
+        # with --spp n^2 a frame is n^2 launch pairs: counts are per LAUNCH (averaged over the sub-frames), like the kernel times
+        sc = dict(sc)
+        for k in ("hit_rays", "node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow"):
+            sc[k] = sc[k] // args.spp
         pixels = W * rows
         hits, miss = sc["hit_rays"], pixels - sc["hit_rays"]
         items = hits * L
@@ -240,7 +246,7 @@ def main():
                        else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
                              else f"main_nocats: the scene of the reference's main() (ground cube, bunny, 3 textured trees; the cats are a missing blob), "
                                   f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[3] shape]" if args.workload == "main_nocats"
-                             else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s) [BASELINE.json configs[4], spp 1]"),
+                             else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s), spp {args.spp} [BASELINE.json configs[4]]"),
                        "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
