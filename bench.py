@@ -215,6 +215,8 @@ def main():
         sc = dict(sc)
         for k in ("hit_rays", "node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow"):
             sc[k] = sc[k] // args.spp
+        if args.spp > 1:        # the event pair around the traversal spans all sub-frames: per launch = / spp (includes the small shade / accumulate launches in between)
+            st = dict(st); st["ms_primary"] = st["ms_primary"] / args.spp
         pixels = W * rows
         hits, miss = sc["hit_rays"], pixels - sc["hit_rays"]
         items = hits * L
