@@ -294,7 +294,6 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
-    for (int i = 0; i < RING * 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i / 4][i % 4]);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
@@ -466,6 +465,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
 
     // SRT_FLAG_NO_TIMING: no event records (a caller capturing the launches into a hipGraph)
     hipEvent_t* ev = (p->flags & SRT_FLAG_NO_TIMING) ? nullptr : s->ev[s->ring_count % RING];
+    if (ev && !ev[0]) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));      // a ring slot's events are made on first use
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (spp == 1) {
         rc = launch_frame(dp, d_hit_id, d_t, d_rgb_linear, d_rgb8, ctr_next, ev);
