@@ -459,3 +459,38 @@ def test_adversarial_scenes_match_oracle(srt, oracle, seed):
         assert np.abs(o["rgb_linear"][fin] - c["rgb_linear"][fin]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"][fin]).max()))
         assert o["stats"]["node_tests_primary"] == c["stats"]["node_tests_primary"] and o["stats"]["tri_tests_primary"] == c["stats"]["tri_tests_primary"]
         assert o["stats"]["node_tests_shadow"] == c["stats"]["node_tests_shadow"]
+
+
+@pytest.mark.parametrize("n_obj,L", [(40, 1), (40, 9), (70, 64), (3, 100)])
+def test_many_objects_and_light_groups(srt, oracle, n_obj, L):
+    """Object loops run in groups (roots of up to 16 objects are queued at once, 4 with 64 shadow rays in flight) and light
+    samples in groups of 64: scenes with more objects / samples than one group, through the shipped kernels (16 shadow rays
+    per round below 8 samples, 64 from 8 on) and the counting build, against the oracle."""
+    from simple_raytracer_amd import host
+    import scenes
+    rng = np.random.default_rng(100 + n_obj + L)
+    cube = gu.load_mesh("cube")
+    recipe = scenes.Recipe(); meshes = {"cube": cube}
+    T = host.Transformation
+    for k in range(n_obj):
+        name = f"c{k}"
+        recipe.load(name, "cube"); recipe.color(name, rng.uniform(0.1, 1, 3))
+        s = float(rng.uniform(4, 14))
+        recipe.transform(name, T.scaleObj(s, s * float(rng.uniform(0.5, 2)), s))
+        recipe.transform(name, T.rotateObjY(float(rng.uniform(0, 3))))
+        recipe.transform(name, T.changeObjPosition(float(rng.uniform(-110, 110)), float(rng.uniform(-70, 70)), float(rng.uniform(180, 420))))
+        recipe.bvh(name)
+    recipe.light = (250.0, -300.0, -50.0)
+    flat = host.build_flat_scene(recipe, meshes)
+    assert flat.n_objects == n_obj
+    ds = srt.DeviceScene(flat)
+    W, H = 144, 96
+    lights = abi.light_staircase(recipe.light, L)
+    c = oracle.render(flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
+    assert (c["hit_id"] >= 0).sum() > 300
+    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8):          # shipped fused, counting build, unfused
+        o = ds.render(abi.make_params(W, H, lights, flags=flags))
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
+        assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
+        check_rgb8(o["rgb8"], c["rgb8"])
+        assert o["stats"]["shadow_rays"] == c["stats"]["shadow_rays"]
