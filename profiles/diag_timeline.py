@@ -21,22 +21,26 @@ for variant in (0,):
     closest = d[:, 0].astype(np.float64)
     hw = d[:, 5]
     k0 = d[:, 6].astype(np.int64); k1 = d[:, 7].astype(np.int64)
+    cu_ = ((hw >> np.uint64(8)) & np.uint64(0xf)).astype(np.int64); se_ = ((hw >> np.uint64(13)) & np.uint64(0x7)).astype(np.int64)
     xcc_ = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
-    for x in np.unique(xcc_):                       # each XCD has its own clock base
-        m = xcc_ == x
+    slot_ = (xcc_ * 8 + se_) * 16 + cu_
+    # clocks are only comparable inside one CU: align every CU to its own first stamp, then look at the average CU
+    span = 0
+    for c in np.unique(slot_):
+        m = slot_ == c
         base = k0[m].min(); k0[m] -= base; k1[m] -= base
-    t0 = 0; span = k1.max()
+        span = max(span, int(k1[m].max()))
+    n_cu = len(np.unique(slot_))
     dur = (k1 - k0).astype(np.float64)
-    print(f"variant {variant}: kernel {o['stats']['ms_primary']*1e3 + o['stats']['ms_shadow']*1e3:.1f} us (stamped build); stamp span {span} ticks; "
-          f"sum of wave durations {dur.sum()/1e6:.1f} M ticks; closest-hit part {closest.sum()/1e6:.1f} M; mean busy waves {dur.sum()/span:.0f}")
+    print(f"variant {variant}: kernel {o['stats']['ms_primary']*1e3 + o['stats']['ms_shadow']*1e3:.1f} us (stamped build); longest CU span {span} ticks; "
+          f"sum of wave durations {dur.sum()/1e6:.1f} M ticks; closest-hit part {closest.sum()/1e6:.1f} M")
     print(f"   duration percentiles (ticks): 50% {np.percentile(dur,50):.0f}  90% {np.percentile(dur,90):.0f}  99% {np.percentile(dur,99):.0f}  max {dur.max():.0f}")
-    # busy waves per 5 % of the kernel's span
     edges = np.linspace(0, span, 21)
     busy = []
     for a, b in zip(edges[:-1], edges[1:]):
-        ov = np.clip(np.minimum(k1 - t0, b) - np.maximum(k0 - t0, a), 0, None)
-        busy.append(ov.sum() / (b - a))
-    print("   busy waves per 5% slice: " + " ".join(f"{x:.0f}" for x in busy))
+        ov = np.clip(np.minimum(k1, b) - np.maximum(k0, a), 0, None)
+        busy.append(ov.sum() / (b - a) / n_cu)
+    print("   busy waves per CU (of 24 slots) in each 5% slice of the span: " + " ".join(f"{x:.1f}" for x in busy))
     cu = (hw >> np.uint64(8)) & np.uint64(0xf); se = (hw >> np.uint64(13)) & np.uint64(0x7); xcc = (hw >> np.uint64(32)) & np.uint64(0xf)
     slot = (xcc.astype(np.int64) * 8 + se.astype(np.int64)) * 16 + cu.astype(np.int64)
     per_cu = np.bincount(slot, weights=dur)
