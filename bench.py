@@ -258,6 +258,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,
                          "algorithmic_bytes_per_launch": kern[dom]["bytes"], "kernel_ms": round(kern[dom]["ms"], 5),
+                         "valu": measured_valu(args.workload, dom, W, H, L) if world == 1 else None,
                          "note": "algorithmic bytes = 32 B x slab tests + 36 B x triangle tests (+ per-pixel output bytes) of the "
                                  f"kernel's own traversal; the scene ({(g.flat.n_nodes * 32 + g.flat.n_tris * 96) / 1e6:.1f} MB of node and triangle records) is "
                                  "L2 / Infinity-Cache resident, so this is an effective rate that can exceed the HBM peak"},
@@ -294,6 +295,20 @@ def measured_traffic(workload, kernel, W, H, L):
     with open(path) as f:
         t = json.load(f)
     return t.get(f"{workload}_{W}x{H}_L{L}", {}).get(kernel)
+
+
+def measured_valu(workload, kernel, W, H, L):
+    """VALU issue utilisation of `kernel` from the committed PMC passes: a wave64 VALU instruction holds its SIMD for 4
+    cycles, the chip has 256 CUs x 4 SIMDs.  None when this workload was not profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        v = json.load(f).get(f"{workload}_{W}x{H}_L{L}", {}).get("_valu", {}).get(kernel)
+    if not v or not v.get("cycles"):
+        return None
+    return {"wave_insts_per_launch": v["insts"], "launch_cycles": v["cycles"], "lanes_active_of_64": v.get("lanes_active"),
+            "issue_frac": round(v["insts"] * 4 / (1024 * v["cycles"]), 4), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
 
 
 def cpu_reference(g, W, H):

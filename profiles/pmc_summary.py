@@ -27,4 +27,9 @@ if len(sys.argv) > 3:
         f = acc[k].get("FETCH_SIZE"); w = acc[k].get("WRITE_SIZE")
         if f and w:
             t[key][name] = int(2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w))
+        # VALU issue: wave-instructions per launch and the launch's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        v = acc[k].get("SQ_INSTS_VALU"); c = acc[k].get("GRBM_GUI_ACTIVE"); th = acc[k].get("SQ_THREAD_CYCLES_VALU")
+        if v and c:
+            t[key].setdefault("_valu", {})[name] = {"insts": int(sum(v) / len(v)), "cycles": int(sum(c) / len(c) / 8),
+                                                    "lanes_active": round(sum(th) / len(th) / (sum(v) / len(v)), 1) if th else None}
     json.dump(t, open(out, "w"), indent=1, sort_keys=True)
