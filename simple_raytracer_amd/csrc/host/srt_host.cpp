@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <array>
 #include <thread>
+#include <memory>
+#include <sys/stat.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -550,9 +552,43 @@ std::string trim(const std::string& s) {
 }
 } // namespace
 
+// The reference's main() loads every OBJ again for every frame of the orbit (simple_raytracer.cpp:534-618); parsing the
+// bunny and decoding a 1024x1024 JPEG cost more than building the hierarchies and rendering the frame.  A parsed asset
+// is therefore kept per process, keyed by path and valid while the OBJ file's size and modification time are unchanged
+// (its MTL and texture files are assumed to change with it); SRT_HOST_NO_ASSET_CACHE=1 turns the cache off.
+namespace {
+struct CachedAsset {
+    long long mtime_ns = 0, size = 0;
+    std::vector<Triangle> triangles;
+    std::vector<std::pair<std::string, Texture>> textures;     // diffuse maps this OBJ's materials name, decoded
+    std::vector<std::string> failed;                            // ... and the ones that did not decode
+};
+std::mutex g_asset_mu;
+std::unordered_map<std::string, std::shared_ptr<const CachedAsset>> g_assets;
+bool file_stamp(const std::string& path, long long& mtime_ns, long long& size) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return false;
+    mtime_ns = (long long)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec; size = (long long)st.st_size;
+    return true;
+}
+bool asset_cache_enabled() { const char* e = std::getenv("SRT_HOST_NO_ASSET_CACHE"); return !(e && *e && *e != '0'); }
+} // namespace
+
 void ObjectManager::loadObjFile(const std::string& objFilename) {
     objColors[objFilename] = vec3(1.f, 0.f, 0.f);                        // :29
     objProperties[objFilename] = vec3(0.2f, 0.5f, 15.0f);                // :31-34
+    long long stamp_mtime = 0, stamp_size = 0;
+    const bool cacheable = asset_cache_enabled() && file_stamp(objFilename, stamp_mtime, stamp_size);
+    if (cacheable) {
+        std::shared_ptr<const CachedAsset> hit;
+        { std::lock_guard<std::mutex> g(g_asset_mu); auto it = g_assets.find(objFilename); if (it != g_assets.end()) hit = it->second; }
+        if (hit && hit->mtime_ns == stamp_mtime && hit->size == stamp_size) {
+            for (const auto& t : hit->textures) if (!textureData.count(t.first)) textureData[t.first] = t.second;
+            for (const std::string& f : hit->failed) if (!textureData.count(f)) std::cerr << "Failed to load texture: " << f << std::endl;
+            objTriangles[objFilename] = hit->triangles;
+            return;
+        }
+    }
     std::vector<float> V, VT, VN;
     std::vector<ObjFace> faces;
     std::vector<std::string> mat_names, mat_tex;
@@ -625,11 +661,21 @@ void ObjectManager::loadObjFile(const std::string& objFilename) {
         }
     }
 
+    std::shared_ptr<CachedAsset> fresh = cacheable ? std::make_shared<CachedAsset>() : nullptr;
     for (const std::string& texturePath : mat_tex) {                      // :52-68
-        if (texturePath.empty() || textureData.count(texturePath)) continue;
+        if (texturePath.empty()) continue;
+        if (textureData.count(texturePath)) {
+            if (fresh) fresh->textures.emplace_back(texturePath, textureData[texturePath]);
+            continue;
+        }
         Texture t;
-        if (load_texture(texturePath, t)) textureData[texturePath] = std::move(t);
-        else std::cerr << "Failed to load texture: " << texturePath << std::endl;
+        if (load_texture(texturePath, t)) {
+            if (fresh) fresh->textures.emplace_back(texturePath, t);
+            textureData[texturePath] = std::move(t);
+        } else {
+            if (fresh) fresh->failed.push_back(texturePath);
+            std::cerr << "Failed to load texture: " << texturePath << std::endl;
+        }
     }
 
     std::vector<Triangle> triangles;
@@ -666,7 +712,12 @@ void ObjectManager::loadObjFile(const std::string& objFilename) {
         }
         triangles.push_back(tria);
     }
-    objTriangles[objFilename] = triangles;
+    if (fresh) {
+        fresh->mtime_ns = stamp_mtime; fresh->size = stamp_size; fresh->triangles = triangles;
+        std::lock_guard<std::mutex> g(g_asset_mu);
+        g_assets[objFilename] = fresh;
+    }
+    objTriangles[objFilename] = std::move(triangles);
 }
 
 const std::vector<Triangle>& ObjectManager::getTriangles(const std::string& objFilename) const { return objTriangles.at(objFilename); }

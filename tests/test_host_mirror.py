@@ -132,6 +132,22 @@ def test_obj_loader_own_asset(host, tmp_path):
     assert np.array_equal(nrm[2, :3], [0, 0, 1]) and ht.sum() == 0
 
 
+def test_parsed_assets_are_cached_until_the_file_changes(host, tmp_path):
+    """loadObjFile keeps a parsed OBJ per process (the reference's main() loads every asset again for every frame): a
+    second load gives the same triangles, a rewritten file is parsed again."""
+    p = tmp_path / "a.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    a = host.ObjectManager(); a.loadObjFile(str(p))
+    b = host.ObjectManager(); b.loadObjFile(str(p))
+    assert np.array_equal(bits(a.points(str(p))), bits(b.points(str(p)))) and a.num_tris(str(p)) == 1
+    b.transformTriangles(str(p), host.Transformation.scaleObj(2.0, 2.0, 2.0))       # a loaded copy is the caller's own
+    c = host.ObjectManager(); c.loadObjFile(str(p))
+    assert np.array_equal(bits(a.points(str(p))), bits(c.points(str(p))))
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 5\nf 1 2 3\nf 1 2 4\n")          # size (and time) change: parsed again
+    d = host.ObjectManager(); d.loadObjFile(str(p))
+    assert d.num_tris(str(p)) == 2
+
+
 def test_polygon_faces_are_cut_like_tinyobj_earcut(host, tmp_path):
     """Faces with more than four corners: the reference's loader is tinyobjloader built with mapbox earcut
     (simple_raytracer.cpp:15-16).  tests/golden/polygons.npz: 29 faces of 5..120 corners (concave, both windings,
