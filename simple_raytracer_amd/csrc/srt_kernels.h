@@ -340,28 +340,33 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
 #ifdef SRT_DIAG
         unsigned long long c0, c1; SRT_STAMP(c0); dg_batches++; dg_titems += m;
 #endif
-        if (lane < m) {
-            const uint32_t info = tq[2 * (tqn + lane)], pl = tq[2 * (tqn + lane) + 1];
+        // a batch that does not fill the wave (the flush at the end of a tile: 16 rays x a leaf or two) is spread over
+        // sub-lanes: S lanes share one (leaf, ray) pair and take every S-th triangle; the merge below does not care who
+        // found the minimum.  A full batch has S = 1: one pair per lane, triangles k and k + 1 per iteration.
+        const uint32_t sh = m <= 8 ? 3u : (m <= 16 ? 2u : (m <= 32 ? 1u : 0u));
+        const uint32_t S = 1u << sh, pi = lane >> sh, sub = lane & (S - 1u);
+        if (pi < m) {
+            const uint32_t info = tq[2 * (tqn + pi)], pl = tq[2 * (tqn + pi) + 1];
             const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
             const float4 dxy = dir[pl];
             const V3 d = mk(dxy.x, dxy.y, p.focal);
             float bt = __builtin_inff();
             uint32_t bi = 0;
             // two triangles per iteration: their Moller-Trumbore chains are independent and interleave (the chain of a
-            // single test is ~100 dependent VALU ops); the update order keeps the first minimum
-            const float4* tp = reinterpret_cast<const float4*>(s.tris_o) + (size_t)first * 3;
-            for (uint32_t k = 0; k < cnt; k += 2) {
-                const bool two = k + 1 < cnt;
+            // single test is ~100 dependent VALU ops); ids rise inside a lane, so strict '<' keeps the first minimum
+            const float4* base = reinterpret_cast<const float4*>(s.tris_o) + (size_t)first * 3;
+            for (uint32_t k = sub; k < cnt; k += 2 * S) {
+                const bool two = k + S < cnt;
+                const float4* tp = base + (size_t)k * 3;
                 const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                const float4* tq_ = two ? tp + 3 : tp;
+                const float4* tq_ = two ? tp + 3 * S : tp;
                 const float4 b0 = tq_[0], b1 = tq_[1], b2 = tq_[2];
-                tp += 6;
                 if (COUNT) n_tri += two ? 2 : 1;
                 const float ta = ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
                 const float tb_ = ray_triangle_origin(d, mk(b0.x, b0.y, b0.z), mk(b0.w, b1.x, b1.y), mk(b1.z, b1.w, b2.x), mk(b2.y, b2.z, b2.w));
                 // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
                 if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
-                if (two && tb_ != SRT_NEG_INF && tb_ < bt) { bt = tb_; bi = first + k + 1; }
+                if (two && tb_ != SRT_NEG_INF && tb_ < bt) { bt = tb_; bi = first + k + S; }
             }
             if (bt < __builtin_inff()) {
                 const uint32_t tb = (bt == 0.0f) ? 0u : __float_as_uint(bt);     // -0.0 ties with +0.0
