@@ -136,3 +136,17 @@ def test_supersampling_extension_definition(oracle):
     assert np.median(np.abs(o4["rgb_linear"][same] - o1["rgb_linear"][same])) < 1e-3
     with pytest.raises(RuntimeError):
         oracle.render(g.flat, g.params(W, H, L, spp=2))
+
+
+def test_emitted_pixel_counts_of_the_survey(oracle):
+    """SURVEY.md s8(c) lists, for renders made with the compiled reference during the survey, how many pixels
+    sendRaysAndIntersectPointsColors emitted (non-black pixels, :518): an independent pin of the scene scripts, camera
+    conventions and the hit / shading path.  (Its FNV hashes of the pixel stream are not reproduced here: the survey does
+    not pin down the byte layout that was hashed; the pixel goldens of tests/golden/ play that role.)"""
+    for name, W, H, want in (("cube", 256, 256, 41606), ("sphere", 256, 256, 3651),
+                             ("ground_bunny", 600, 400, 118548), ("ground_bunny", 1920, 1080, 785274)):
+        g = gu.GoldenScene(name)
+        p = g.params(W, H, 1)
+        p.background[0] = p.background[1] = p.background[2] = 0          # black = "not emitted"
+        o = oracle.render(g.flat, p)
+        assert int((o["rgb8"].reshape(-1, 3).max(1) > 0).sum()) == want, (name, W, H)
