@@ -916,6 +916,50 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     int32_t id; float t; V3 d;
     unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
     SRT_STAMP(k0);
+    if (!COUNT) {
+        // Background tiles: most of a typical frame, and a wave that only learns that its 16 rays miss every object costs
+        // ~150 VALU instructions of set-up, queueing and write-out.  So wave 0 first puts the tile's 64 rays (one per lane)
+        // through the slab test of every object's root box -- the very test the first node step of each ray would run --
+        // while the other three waves wait at the launch-time barrier; if no ray passes any root, it writes the 64
+        // background pixels and the tile's (all-clear) shadow words with full lanes and the workgroup is done.
+        __shared__ uint32_t tile_live;
+        if (wave == 0) {
+            const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
+            const uint32_t px = blockIdx.x * 8 + (quad & 1) * 4 + (ql & 3), r = blockIdx.y * 8 + (quad >> 1) * 4 + (ql >> 2);
+            const bool live = px < p.W && r < p.rows;
+            const V3 o = mk(0.f, 0.f, 0.f);
+            const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
+            const RayRcp rc = ray_rcp(dd);
+            const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+            bool any = false;
+            for (uint32_t ob = 0; ob < s.n_objects; ob++) {
+                const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
+                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+                bool pass;
+                if (FILTER) {
+                    bool amb;
+                    pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                    if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+                } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+                any |= pass;
+            }
+            const unsigned long long m = __ballot(live && any);
+            if (lane == 0) tile_live = m != 0ull;
+            if (m == 0ull) {
+                if (live) {      // what closest_hit_phase writes for a miss (:518, drawImage:476-487)
+                    const size_t pix = (size_t)r * p.W + px;
+                    hit_id[pix] = -1;
+                    t_out[pix] = __builtin_inff();
+                    if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+                    if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+                }
+                const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                for (uint32_t l = lane; l < p.n_lights; l += 64) shadow_bits[tile_index * p.n_lights + l] = 0ull;
+            }
+        }
+        __syncthreads();                 // at launch: nobody has work to wait behind yet
+        if (!tile_live) return;
+    }
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
     __builtin_amdgcn_wave_barrier();
