@@ -107,7 +107,9 @@ typedef struct srt_params {
                                     * regular n x n sub-pixel grid, offsets (k+0.5)/n - 0.5 added to dir.xy, the
                                     * sub-frames' pre-tone-map sums added in order, divided by spp, tone-mapped
                                     * once; hit_id / t report sub-sample 0                            */
-    uint32_t flags;
+    uint32_t flags;                /* SRT_FLAG_* in bits 0..7; bits 8..15: kernel-variant selector for A/B measurements and
+                                    * the parity tests (0 = the shipped pipeline; the others compute the same results with
+                                    * older or differently configured kernels, DESIGN.md s5 lists them)                  */
 } srt_params;
 
 typedef struct srt_stats {
