@@ -37,6 +37,10 @@ struct HuffTable {
     int32_t mincode[17], maxcode[17], valptr[17];
     uint8_t look_len[512];      // 9-bit prefix -> code length (0 = longer than 9 bits)
     uint8_t look_val[512];
+    HuffTable() {               // a table a scan names without a DHT having defined it decodes nothing
+        std::memset(vals, 0, sizeof vals); std::memset(look_len, 0, sizeof look_len); std::memset(look_val, 0, sizeof look_val);
+        for (int i = 0; i < 17; i++) { mincode[i] = 0; maxcode[i] = -1; valptr[i] = 0; }
+    }
     bool build(const uint8_t counts[16], const uint8_t* symbols, int n) {
         std::memcpy(vals, symbols, (size_t)n);
         std::memset(look_len, 0, sizeof look_len);
@@ -429,21 +433,26 @@ bool Jpeg::scan_data() {
 }
 
 // ---- inverse DCT (stb_image.h:2430-2519) -------------------------------------------------------------------
-inline int fx(float x) { return (int)((double)x * 4096 + 0.5); }
-struct Idct1D { int x0, x1, x2, x3, t0, t1, t2, t3; };
-inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-    static const int C0 = fx(0.5411961f), C1 = fx(-1.847759065f), C2 = fx(0.765366865f), C3 = fx(1.175875602f),
-                     C4 = fx(0.298631336f), C5 = fx(2.053119869f), C6 = fx(3.072711026f), C7 = fx(1.501321110f),
-                     C8 = fx(-0.899976223f), C9 = fx(-2.562915447f), C10 = fx(-1.961570560f), C11 = fx(-0.390180644f);
+// All arithmetic in uint32_t: for sane coefficients it is the signed arithmetic of the original, for corrupt ones it wraps
+// like two's complement hardware does instead of being undefined.  sra() is the arithmetic right shift of the signed value.
+inline uint32_t fx(float x) { return (uint32_t)(int32_t)((double)x * 4096 + 0.5); }
+inline int32_t sra(uint32_t v, int n) { return (int32_t)v >> n; }
+struct Idct1D { uint32_t x0, x1, x2, x3, t0, t1, t2, t3; };
+inline Idct1D idct_1d(int32_t s0_, int32_t s1_, int32_t s2_, int32_t s3_, int32_t s4_, int32_t s5_, int32_t s6_, int32_t s7_) {
+    static const uint32_t C0 = fx(0.5411961f), C1 = fx(-1.847759065f), C2 = fx(0.765366865f), C3 = fx(1.175875602f),
+                          C4 = fx(0.298631336f), C5 = fx(2.053119869f), C6 = fx(3.072711026f), C7 = fx(1.501321110f),
+                          C8 = fx(-0.899976223f), C9 = fx(-2.562915447f), C10 = fx(-1.961570560f), C11 = fx(-0.390180644f);
+    const uint32_t s0 = (uint32_t)s0_, s1 = (uint32_t)s1_, s2 = (uint32_t)s2_, s3 = (uint32_t)s3_,
+                   s4 = (uint32_t)s4_, s5 = (uint32_t)s5_, s6 = (uint32_t)s6_, s7 = (uint32_t)s7_;
     Idct1D r;
-    int p1 = (s2 + s6) * C0;
-    int t2 = p1 + s6 * C1, t3 = p1 + s2 * C2;
-    int t0 = (s0 + s4) * 4096, t1 = (s0 - s4) * 4096;
+    uint32_t p1 = (s2 + s6) * C0;
+    uint32_t t2 = p1 + s6 * C1, t3 = p1 + s2 * C2;
+    uint32_t t0 = (s0 + s4) * 4096u, t1 = (s0 - s4) * 4096u;
     r.x0 = t0 + t3; r.x3 = t0 - t3; r.x1 = t1 + t2; r.x2 = t1 - t2;
     t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-    int p3 = t0 + t2, p4 = t1 + t3;
-    p1 = t0 + t3; int p2 = t1 + t2;
-    const int p5 = (p3 + p4) * C3;
+    uint32_t p3 = t0 + t2, p4 = t1 + t3;
+    p1 = t0 + t3; uint32_t p2 = t1 + t2;
+    const uint32_t p5 = (p3 + p4) * C3;
     t0 *= C4; t1 *= C5; t2 *= C6; t3 *= C7;
     p1 = p5 + p1 * C8; p2 = p5 + p2 * C9; p3 *= C10; p4 *= C11;
     r.t3 = t3 + p1 + p4; r.t2 = t2 + p2 + p3; r.t1 = t1 + p2 + p4; r.t0 = t0 + p1 + p3;
@@ -452,24 +461,24 @@ inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, in
 inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
 void Jpeg::idct(uint8_t* out, int stride, const int16_t d[64]) {
-    int v[64];
+    int32_t v[64];
     for (int i = 0; i < 8; i++) {                      // columns, 2 extra bits kept
         Idct1D r = idct_1d(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
         r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
-        v[i] = (r.x0 + r.t3) >> 10;      v[56 + i] = (r.x0 - r.t3) >> 10;
-        v[8 + i] = (r.x1 + r.t2) >> 10;  v[48 + i] = (r.x1 - r.t2) >> 10;
-        v[16 + i] = (r.x2 + r.t1) >> 10; v[40 + i] = (r.x2 - r.t1) >> 10;
-        v[24 + i] = (r.x3 + r.t0) >> 10; v[32 + i] = (r.x3 - r.t0) >> 10;
+        v[i] = sra(r.x0 + r.t3, 10);      v[56 + i] = sra(r.x0 - r.t3, 10);
+        v[8 + i] = sra(r.x1 + r.t2, 10);  v[48 + i] = sra(r.x1 - r.t2, 10);
+        v[16 + i] = sra(r.x2 + r.t1, 10); v[40 + i] = sra(r.x2 - r.t1, 10);
+        v[24 + i] = sra(r.x3 + r.t0, 10); v[32 + i] = sra(r.x3 - r.t0, 10);
     }
     for (int i = 0; i < 8; i++, out += stride) {       // rows: >> 17 rounds, +128 level shift folded in
-        const int* w = v + 8 * i;
+        const int32_t* w = v + 8 * i;
         Idct1D r = idct_1d(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
-        const int bias = 65536 + (128 << 17);
+        const uint32_t bias = 65536u + (128u << 17);
         r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
-        out[0] = clamp8((r.x0 + r.t3) >> 17); out[7] = clamp8((r.x0 - r.t3) >> 17);
-        out[1] = clamp8((r.x1 + r.t2) >> 17); out[6] = clamp8((r.x1 - r.t2) >> 17);
-        out[2] = clamp8((r.x2 + r.t1) >> 17); out[5] = clamp8((r.x2 - r.t1) >> 17);
-        out[3] = clamp8((r.x3 + r.t0) >> 17); out[4] = clamp8((r.x3 - r.t0) >> 17);
+        out[0] = clamp8(sra(r.x0 + r.t3, 17)); out[7] = clamp8(sra(r.x0 - r.t3, 17));
+        out[1] = clamp8(sra(r.x1 + r.t2, 17)); out[6] = clamp8(sra(r.x1 - r.t2, 17));
+        out[2] = clamp8(sra(r.x2 + r.t1, 17)); out[5] = clamp8(sra(r.x2 - r.t1, 17));
+        out[3] = clamp8(sra(r.x3 + r.t0, 17)); out[4] = clamp8(sra(r.x3 - r.t0, 17));
     }
 }
 
