@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/srt.h"
@@ -256,7 +257,23 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     if (rc != SRT_OK) return rc;
     std::vector<DevTri> tris(d->n_tris);
     std::vector<DevTriO> tris_o(d->n_tris);
-    for (uint32_t i = 0; i < d->n_tris; i++) { tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i); tris_o[i] = derive_triangle_origin(tris[i]); }
+    {   // per-triangle records: independent, so big scenes are cut over a few host threads (a scene made per frame by a
+        // drop-in caller spends more time here than in the render)
+        auto derive_range = [&](uint32_t b, uint32_t e) {
+            for (uint32_t i = b; i < e; i++) { tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i); tris_o[i] = derive_triangle_origin(tris[i]); }
+        };
+        const uint32_t n = d->n_tris;
+        unsigned hc = std::thread::hardware_concurrency();
+        const uint32_t T = n < 32768 ? 1u : (hc >= 8 ? 8u : (hc >= 2 ? hc : 1u));
+        if (T == 1) derive_range(0, n);
+        else {
+            std::vector<std::thread> th;
+            const uint32_t step = (n + T - 1) / T;
+            for (uint32_t k = 1; k < T; k++) th.emplace_back(derive_range, k * step < n ? k * step : n, (k + 1) * step < n ? (k + 1) * step : n);
+            derive_range(0, step < n ? step : n);
+            for (std::thread& t : th) t.join();
+        }
+    }
 
     HIP_TRY(hipSetDevice(device));
     srt_scene* s = new (std::nothrow) srt_scene();
