@@ -29,6 +29,7 @@ row(order[:10000], "top 10000")
 row(order, "all")
 light = np.where(steps <= 1)[0]
 row(light, "<=1 step")
+row(np.where(steps == 2)[0], "2 steps")
 print("per node step (top 1000):  test %.0f cyc, commit+push %.0f cyc;  per tri batch %.0f cyc" % (
     test[order[:1000]].sum() / steps[order[:1000]].sum(), commit[order[:1000]].sum() / steps[order[:1000]].sum(), tri[order[:1000]].sum() / batches[order[:1000]].sum()))
 top = order[:1000]
