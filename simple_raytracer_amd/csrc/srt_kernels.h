@@ -354,19 +354,16 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             uint32_t bi = 0;
             // two triangles per iteration: their Moller-Trumbore chains are independent and interleave (the chain of a
             // single test is ~100 dependent VALU ops); ids rise inside a lane, so strict '<' keeps the first minimum
-            const float4* base = reinterpret_cast<const float4*>(s.tris_o) + (size_t)first * 3;
-            for (uint32_t k = sub; k < cnt; k += 2 * S) {
-                const bool two = k + S < cnt;
-                const float4* tp = base + (size_t)k * 3;
-                const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                const float4* tq_ = two ? tp + 3 * S : tp;
-                const float4 b0 = tq_[0], b1 = tq_[1], b2 = tq_[2];
-                if (COUNT) n_tri += two ? 2 : 1;
+            const float4* tp = reinterpret_cast<const float4*>(s.tris_o) + ((size_t)first + sub) * 3;
+            float4 n0, n1, n2;
+            if (sub < cnt) { n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
+            for (uint32_t k = sub; k < cnt; k += S) {
+                const float4 a0 = n0, a1 = n1, a2 = n2;
+                if (k + S < cnt) { tp += 3 * S; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }      // the next triangle's record is in flight during this test
+                if (COUNT) n_tri++;
                 const float ta = ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
-                const float tb_ = ray_triangle_origin(d, mk(b0.x, b0.y, b0.z), mk(b0.w, b1.x, b1.y), mk(b1.z, b1.w, b2.x), mk(b2.y, b2.z, b2.w));
                 // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
                 if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
-                if (two && tb_ != SRT_NEG_INF && tb_ < bt) { bt = tb_; bi = first + k + S; }
             }
             if (bt < __builtin_inff()) {
                 const uint32_t tb = (bt == 0.0f) ? 0u : __float_as_uint(bt);     // -0.0 ties with +0.0
