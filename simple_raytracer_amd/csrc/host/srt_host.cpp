@@ -751,6 +751,73 @@ void ObjectManager::transformTriangles(const std::string& objFilename, const mat
 namespace {
 struct KeyIdx { float key; uint32_t idx; };
 
+// std::sort as libstdc++ runs it, with its independent halves on different threads.  The order std::sort leaves equal keys
+// in is the reference's leaf order, so the result has to be libstdc++'s to the element: introsort = quicksort (pivot =
+// median of first + 1, middle, last - 1 moved to the front; Hoare-style unguarded partition around it), recursing into the
+// right part and looping on the left, 2 * floor(log2 n) levels deep before it falls back to heapsort, ranges of <= 16 left
+// for one final insertion-sort pass.  The right part and the left part never touch each other's elements, so the recursion
+// runs as a pool task and the final pass runs when all tasks are done -- the same comparisons on the same ranges, in another
+// order in time.  tests/test_host_mirror.py compares it with std::sort on arrays full of equal keys.
+struct ExactSort {
+    std::atomic<int> pending{0};
+    static bool less(const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; }
+    static void median_to_first(KeyIdx* result, KeyIdx* a, KeyIdx* b, KeyIdx* c) {
+        if (less(*a, *b)) {
+            if (less(*b, *c)) std::iter_swap(result, b);
+            else if (less(*a, *c)) std::iter_swap(result, c);
+            else std::iter_swap(result, a);
+        } else if (less(*a, *c)) std::iter_swap(result, a);
+        else if (less(*b, *c)) std::iter_swap(result, c);
+        else std::iter_swap(result, b);
+    }
+    static KeyIdx* partition(KeyIdx* first, KeyIdx* last, KeyIdx* pivot) {
+        for (;;) {
+            while (less(*first, *pivot)) ++first;
+            --last;
+            while (less(*pivot, *last)) --last;
+            if (!(first < last)) return first;
+            std::iter_swap(first, last);
+            ++first;
+        }
+    }
+    void loop(KeyIdx* first, KeyIdx* last, int depth_limit) {
+        while (last - first > 16) {
+            if (depth_limit == 0) { std::partial_sort(first, last, last, less); return; }     // the library's own heapsort fallback
+            --depth_limit;
+            KeyIdx* mid = first + (last - first) / 2;
+            median_to_first(first, first + 1, mid, last - 1);
+            KeyIdx* cut = partition(first + 1, last, first);
+            if (last - cut >= PAR_MIN && BuildPool::get().workers()) {
+                pending.fetch_add(1, std::memory_order_relaxed);
+                BuildPool::get().submit([this, cut, last, depth_limit] { loop(cut, last, depth_limit); pending.fetch_sub(1, std::memory_order_release); });
+            } else loop(cut, last, depth_limit);
+            last = cut;
+        }
+    }
+    static void linear_insert(KeyIdx* last) {
+        KeyIdx val = *last; KeyIdx* next = last - 1;
+        while (less(val, *next)) { *last = *next; last = next; --next; }
+        *last = val;
+    }
+    static void insertion(KeyIdx* first, KeyIdx* last) {
+        if (first == last) return;
+        for (KeyIdx* i = first + 1; i != last; ++i) {
+            if (less(*i, *first)) { KeyIdx val = *i; std::move_backward(first, i, i + 1); *first = val; }
+            else linear_insert(i);
+        }
+    }
+    void sort(KeyIdx* first, KeyIdx* last) {
+        if (first == last) return;
+        int lg = 0; for (size_t n = (size_t)(last - first); n > 1; n >>= 1) lg++;
+        loop(first, last, 2 * lg);
+        while (pending.load(std::memory_order_acquire) > 0)
+            if (!BuildPool::get().run_one()) std::this_thread::yield();
+        if (last - first > 16) { insertion(first, first + 16); for (KeyIdx* i = first + 16; i != last; ++i) linear_insert(i); }
+        else insertion(first, last);
+    }
+    static constexpr ptrdiff_t PAR_MIN = 4096;
+};
+
 struct Builder {
     ObjectManager::Hierarchy& h;
     std::vector<float> p1;          // pointOne xyz per triangle (the sort keys)
@@ -780,7 +847,8 @@ struct Builder {
         const int axis = (sx > sy && sx > sz) ? 0 : ((sy > sx && sy > sz) ? 1 : 2);
         KeyIdx* b = scratch.data() + first;
         for (uint32_t k = 0; k < n; k++) { const uint32_t t = h.order[first + k]; b[k].key = p1[3 * t + axis]; b[k].idx = t; }
-        std::sort(b, b + n, [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; });
+        if (n >= 16384) { ExactSort es; es.sort(b, b + n); }                       // std::sort's result, its partitions in parallel
+        else std::sort(b, b + n, [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; });
         for (uint32_t k = 0; k < n; k++) h.order[first + k] = b[k].idx;
         const uint32_t nl = n / 2, nr = n - nl;
         const int32_t li = node + 1, ri = li + (int32_t)subtree(nl);               // DFS pre-order slots
@@ -802,6 +870,15 @@ struct Builder {
     static constexpr uint32_t PAR_MIN = 2048;    // not worth a task below this
 };
 } // namespace
+
+// test hook: the permutation the builder's parallel sort gives and the one std::sort gives (they must be the same)
+void sort_keys_both_ways(const float* keys, uint32_t n, uint32_t* order_parallel, uint32_t* order_std) {
+    std::vector<KeyIdx> a(n), b(n);
+    for (uint32_t i = 0; i < n; i++) { a[i].key = b[i].key = keys[i]; a[i].idx = b[i].idx = i; }
+    { ExactSort es; es.sort(a.data(), a.data() + n); }
+    std::sort(b.begin(), b.end(), [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; });
+    for (uint32_t i = 0; i < n; i++) { order_parallel[i] = a[i].idx; order_std[i] = b[i].idx; }
+}
 
 void ObjectManager::createBoundingHierarchy(const std::string& objFilename) {
     std::vector<Triangle>& triangles = objTriangles[objFilename];

@@ -74,6 +74,9 @@ int srth_om_clone(void* om_, const char* src, const char* dst) {
 int srth_om_set_color(void* om, const char* name, float r, float g, float b) { GUARD(((ObjectManager*)om)->setColor(name, vec3(r, g, b))) }
 int srth_om_set_props(void* om, const char* name, float ka, float ks, float sh) { GUARD(((ObjectManager*)om)->objProperties[name] = vec3(ka, ks, sh)) }
 int srth_om_transform(void* om, const char* name, const float* m) { GUARD(((ObjectManager*)om)->transformTriangles(name, to_mat(m))) }
+int srth_sort_keys_both_ways(const float* keys, uint32_t n, uint32_t* order_parallel, uint32_t* order_std) {
+    GUARD(sort_keys_both_ways(keys, n, order_parallel, order_std))
+}
 int srth_om_build_bvh(void* om, const char* name) { GUARD(((ObjectManager*)om)->createBoundingHierarchy(name)) }
 int64_t srth_om_num_tris(void* om, const char* name) {
     try { return (int64_t)((ObjectManager*)om)->getTriangles(name).size(); } catch (const std::exception& e) { g_err = e.what(); return -1; }

@@ -33,6 +33,7 @@ def load():
             getattr(L, fn).argtypes = [C.c_void_p, C.c_char_p]
         L.srth_om_add_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p]
         L.srth_om_clone.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.srth_sort_keys_both_ways.argtypes = [_f32p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.srth_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]
         L.srth_om_add_texture.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _u8p]
         L.srth_om_add_textured_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p, _f32p, C.c_char_p]
@@ -220,6 +221,14 @@ class ObjectManager:
         if n < 0:
             raise HostError(self.L.srth_last_error().decode())
         return rgb, int(n)
+
+
+def sort_keys_both_ways(keys):
+    """Test hook: (permutation by the hierarchy builder's parallel sort, permutation by std::sort) of float keys."""
+    keys = _f(keys)
+    a = np.empty(keys.size, np.uint32); b = np.empty(keys.size, np.uint32)
+    _ok(load().srth_sort_keys_both_ways(_p(keys), keys.size, _p(a, C.POINTER(C.c_uint32)), _p(b, C.POINTER(C.c_uint32))))
+    return a, b
 
 
 def decode_image(path):

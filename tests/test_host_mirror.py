@@ -132,6 +132,24 @@ def test_obj_loader_own_asset(host, tmp_path):
     assert np.array_equal(nrm[2, :3], [0, 0, 1]) and ht.sum() == 0
 
 
+def test_parallel_sort_is_std_sort_to_the_element(host):
+    """The hierarchy builder sorts big nodes with its own introsort whose partitions run in parallel; the order it leaves
+    EQUAL keys in must be std::sort's (that order is the reference's leaf order, Object.cpp:193-247).  Arrays full of ties,
+    sorted, reversed, organ-pipe, sizes around the thresholds: same permutation as std::sort."""
+    rng = np.random.default_rng(1)
+    sizes = [1, 2, 15, 16, 17, 33, 100, 4095, 4096, 4097, 5000, 16384, 20000, 69451, 131072]
+    for trial, n in enumerate(sizes * 2):
+        kind = trial % 6
+        if kind == 0: k = rng.normal(size=n)
+        elif kind == 1: k = rng.integers(0, max(2, n // 6), n)              # every key shared by ~6 elements, like first vertices
+        elif kind == 2: k = np.sort(rng.integers(0, 50, n))
+        elif kind == 3: k = np.sort(rng.normal(size=n))[::-1]
+        elif kind == 4: k = np.where(rng.random(n) < 0.9, 1.0, rng.normal(size=n))
+        else: k = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]])
+        a, b = host.sort_keys_both_ways(np.asarray(k, np.float32))
+        assert np.array_equal(a, b), (n, kind)
+
+
 def test_parsed_assets_are_cached_until_the_file_changes(host, tmp_path):
     """loadObjFile keeps a parsed OBJ per process (the reference's main() loads every asset again for every frame): a
     second load gives the same triangles, a rewritten file is parsed again."""
