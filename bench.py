@@ -56,6 +56,11 @@ def main():
                          "GPUs than ranks (ranks share devices, tiles are staged through host memory)")
     ap.add_argument("--emulate-split", default="", help="R/N: time rank R's share of an N-way scanline split on ONE GPU (no collective); "
                                                          "diagnostic for the strong-scaling ceiling, not a bench line")
+    ap.add_argument("--frame-groups", type=int, default=0,
+                    help="N > 1: the frames of a step are dealt to this many groups of ranks, and inside a group every frame is split "
+                         "by scanline blocks (1 = every frame split over all ranks).  Default: the largest divisor of N that divides "
+                         "--frames (36 frames: 2, 4, 4 groups at N = 2, 4, 8), because a whole or half frame fills the chip better "
+                         "than an eighth of one")
     ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
     args = ap.parse_args()
 
@@ -98,7 +103,13 @@ def main():
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
     emu = [int(x) for x in args.emulate_split.split("/")] if args.emulate_split else None
-    split_rank, split_world = (emu if emu else (rank, world))
+    # frames of a step -> FG groups of ranks; scanline blocks of a frame -> the world / FG ranks of a group
+    FG = args.frame_groups if args.frame_groups > 0 else max(f for f in range(1, world + 1) if world % f == 0 and B % f == 0)
+    if world % FG or B % FG:
+        raise SystemExit(f"--frame-groups {FG} must divide --gpus {world} and --frames {B}")
+    per_group = world // FG
+    B_total, B = B, B // FG                      # B: frames THIS rank renders per step
+    split_rank, split_world = (emu if emu else (rank % per_group, per_group))
     p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8, spp=args.spp)
     rows = scene.rows(p)
     dev = torch.device("cuda", local_rank)
@@ -109,8 +120,8 @@ def main():
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
     SLOTS = 2 if world > 1 else 1        # double-buffered tiles: the gather of step s overlaps the rendering of step s+1
-    gather = tiling.FrameGather(W, H, BLOCK_ROWS if world > 1 else H, rank, world, dev, frames=B,
-                                stage_through_host=(args.backend == "gloo"), slots=SLOTS)
+    gather = tiling.FrameGather(W, H, BLOCK_ROWS if per_group > 1 else H, rank, world, dev, frames=B_total,
+                                stage_through_host=(args.backend == "gloo"), slots=SLOTS, frame_groups=FG)
     if emu:
         assert world == 1
         gather.tiles = [torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev)]
@@ -136,7 +147,7 @@ def main():
     # The B renders of a step are launch-bound when a rank owns 1/8 of a frame: capture them once into a hipGraph
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
     graphs = None
-    if not args.no_graph and B % 2 == 0:
+    if not args.no_graph:        # (an odd number of renders per handle leaves the hit counters of replayed frames un-zeroed: only statistics nobody reads)
         p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING, spp=args.spp)
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
@@ -199,16 +210,16 @@ def main():
     scene.render_device(pc, stream=stream, hit_id=hit[0].data_ptr(), t=tbuf[0].data_ptr(), rgb_linear=lin[0].data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
-    rays_rank = sc["primary_rays"] + sc["shadow_rays"]
+    rays_rank = sc["primary_rays"] + sc["shadow_rays"]        # of one of this rank's frames (its scanline blocks)
     if world > 1:
-        rr = torch.tensor([rays_rank, sc["primary_rays"], sc["shadow_rays"]], dtype=torch.float64,
+        rr = torch.tensor([rays_rank / FG, sc["primary_rays"] / FG, sc["shadow_rays"] / FG], dtype=torch.float64,        # summed over ranks: one whole frame
                           device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(rr)
         rays_total, prim_total, shad_total = [float(x) for x in rr.tolist()]
     else:
         rays_total, prim_total, shad_total = float(rays_rank), float(sc["primary_rays"]), float(sc["shadow_rays"])
     ms_step = dt / args.steps * 1e3
-    value = rays_total * B / (dt / args.steps) / 1e6
+    value = rays_total * B_total / (dt / args.steps) / 1e6
 
     if rank == 0:
         # with --spp n^2 a frame is n^2 launch pairs: counts are per LAUNCH (averaged over the sub-frames), like the kernel times
@@ -252,8 +263,11 @@ def main():
                        "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
-                       "parallelism": "1 GPU" if world == 1 else f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic over {world} GPUs + one RCCL gather per step, overlapped with the next step's rendering",
-                       "frames_per_step": B, "ms_per_frame": round(ms_step / B, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + f", {S} stream(s)",
+                       "parallelism": "1 GPU" if world == 1 else
+                                      (f"the {B_total} frames of a step dealt to {FG} group(s) of {per_group} GPU(s); inside a group " +
+                                       (f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic" if per_group > 1 else "whole frames") +
+                                       "; one RCCL gather of all tiles per step, overlapped with the next step's rendering"),
+                       "frames_per_step": B_total, "ms_per_frame": round(ms_step / B_total, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + f", {S} stream(s)",
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,

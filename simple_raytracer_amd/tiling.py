@@ -33,11 +33,19 @@ class FrameGather:
     """
 
     def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1,
-                 stage_through_host=False, slots=1):
+                 stage_through_host=False, slots=1, frame_groups=1):
+        """frame_groups = F: the `frames` of a step are dealt to F groups of R = world / F ranks (frame f belongs to group
+        f % F); inside a group every frame is split into scanline blocks over the group's R ranks.  Rank r is member
+        r % R of group r // R.  F = 1 is the pure scanline split, F = world whole frames per rank."""
+        assert world % frame_groups == 0 and frames % frame_groups == 0, "frame groups must divide the ranks and the frames"
         self.W, self.H, self.block_rows, self.rank, self.world, self.dst = width, height, block_rows, rank, world, dst
-        self.rows_of = [abi.rows_owned(height, block_rows, r, world) for r in range(world)]
+        self.groups, self.per_group = frame_groups, world // frame_groups
+        self.group, self.member = rank // self.per_group, rank % self.per_group
+        self.rows_of = [abi.rows_owned(height, block_rows, r % self.per_group, self.per_group) for r in range(world)]
         self.rows = len(self.rows_of[rank])
         self.max_rows = max(len(r) for r in self.rows_of)
+        self.frames_total = frames
+        frames = frames // frame_groups              # frames this rank renders per step
         self.frames = frames
         self.stage = stage_through_host            # gloo rehearsal on a GPU box: collectives on host copies
         # [frames, rows, W, C]: a step's frames travel in ONE collective (few, large messages suit the
@@ -48,7 +56,7 @@ class FrameGather:
         self._host = [None] * slots
         if rank == dst:
             self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(slots)] if world > 1 else None
-            self.frame = torch.empty((frames, height, width, channels), dtype=dtype, device=device)
+            self.frame = torch.empty((self.frames_total, height, width, channels), dtype=dtype, device=device)
             self.index = [torch.as_tensor(np.asarray(r), dtype=torch.long, device=device) for r in self.rows_of]
         else:
             self.recv, self.frame, self.index = None, None, None
@@ -82,8 +90,8 @@ class FrameGather:
                 self.recv[k][r].copy_(recv[r])
         for r in range(self.world):
             n = len(self.rows_of[r])
-            if n:
-                self.frame.index_copy_(1, self.index[r], self.recv[k][r][:, :n])
+            if n:       # sender r holds rows rows_of[r] of the frames of its group: frames group, group + F, ...
+                self.frame[r // self.per_group :: self.groups].index_copy_(1, self.index[r], self.recv[k][r][:, :n])
         return self.frame
 
     def finish_all(self):

@@ -77,3 +77,59 @@ def test_gather_reassembles_reference_frame(world, block_rows):
     g = gu.GoldenScene("cubes4_a0")
     assert np.array_equal(frame, g.out(W, H, L, "rgb8")), "tiled + gathered frame differs from the reference image"
     assert np.array_equal(hits, g.out(W, H, L, "hit_id"))
+
+
+def _group_worker(rank, world, port, groups, block_rows, W, H, frames, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import golden_util as gu
+        from oracle import pyoracle as po
+        from simple_raytracer_amd import abi, tiling
+        g = gu.GoldenScene("cubes4_a0")
+        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), frames=frames, frame_groups=groups)
+        assert fg.frames == frames // groups and fg.per_group == world // groups
+        # frame f of the step is the scene lit by f + 1 light samples; this rank renders frames group, group + F, ...
+        # and of each only the scanline blocks of its place inside the group
+        for k in range(fg.frames):
+            f = k * groups + fg.group
+            p = tiling.split_params(W, H, abi.light_staircase(g.light, f + 1), fg.member, fg.per_group, block_rows)
+            o = po.render(g.flat, p, n_threads=1)
+            assert o["rgb8"].shape[0] == fg.rows
+            fg.tile[k, : fg.rows].copy_(torch.from_numpy(o["rgb8"]))
+        out = fg.gather()
+        if rank == 0:
+            q.put(out.numpy().copy())
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,groups,block_rows", [(2, 2, 16), (4, 2, 8), (3, 1, 5)])
+def test_frame_groups_reassemble_every_frame(world, groups, block_rows):
+    """bench.py deals the frames of a step to groups of ranks and splits each frame by scanline blocks inside a group:
+    rank 0 must end up with every frame, each identical to the whole-frame render."""
+    import golden_util as gu
+    from oracle import pyoracle as po
+    from simple_raytracer_amd import abi
+    W, H, frames = 96, 64, 4 if groups > 1 else 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, groups, block_rows, W, H, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    g = gu.GoldenScene("cubes4_a0")
+    assert got.shape == (frames, H, W, 3)
+    for f in range(frames):
+        want = po.render(g.flat, abi.make_params(W, H, abi.light_staircase(g.light, f + 1)), n_threads=2)["rgb8"]
+        assert np.array_equal(got[f], want), f"frame {f}"
