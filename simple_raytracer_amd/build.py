@@ -91,8 +91,26 @@ def build_examples(force=False, verbose=False):
     return EXAMPLE_ORBIT
 
 
+EXAMPLE_C = os.path.join(HERE, "..", "examples", "c_abi_minimal")
+
+
+def build_c_example(force=False, verbose=False):
+    """examples/c_abi_minimal: include/srt.h from plain C (gcc), no host mirror."""
+    src = os.path.join(HERE, "..", "examples", "c_abi_minimal.c")
+    if not force and not _stale(EXAMPLE_C, [src, LIB_HIP, os.path.join(HERE, "..", "include", "srt.h")]):
+        return EXAMPLE_C
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-o", EXAMPLE_C, src, "-L" + HERE, "-lsrt_hip", "-Wl,-rpath,$ORIGIN/../simple_raytracer_amd"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("gcc failed for examples/c_abi_minimal")
+    return EXAMPLE_C
+
+
 def build_all(force=False, verbose=False):
-    return [build_hip(force, verbose), build_host(force, verbose), build_examples(force, verbose)]
+    return [build_hip(force, verbose), build_host(force, verbose), build_examples(force, verbose), build_c_example(force, verbose)]
 
 
 def build_diag(verbose=False):
