@@ -241,7 +241,7 @@ def main():
                              bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8),
             "k_shade_tile": dict(ms=st["ms_shade"], bytes=4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8),
         }
-        if args.variant in (0, 11):      # shipped: closest hit + shadow rays in one launch
+        if (args.variant == 0 and L < 8) or args.variant in (11, 17):      # closest hit + shadow rays in one launch (shipped below 8 light samples)
             a, b = kern.pop("k_closest_hit_nq"), kern.pop("k_shadow_nq")
             kern = {"k_trace_nq": dict(ms=st["ms_primary"] + st["ms_shadow"], bytes=a["bytes"] + b["bytes"]), **kern}
         if args.variant == 1:

@@ -440,7 +440,12 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
             const dim3 g_((p->width + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
             if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); \
             else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); } while (0)
-        const bool fused = (variant == 0 || variant > 10) && p->n_lights;
+        // From 8 light samples on: closest hit and shadow rays as two launches, the samples cut into (up to) four chunks over
+        // blockIdx.z.  A wave that walks its 16 pixels x all samples through dense geometry alone outlasts the rest of the
+        // launch (K4 shape: 3.9 -> 2.5 ms per frame; K3 with 16 samples: 0.89 -> 0.64 ms); below 8 the fused kernel wins.
+        const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
+        const bool chunked = p->n_lights >= 8 && !count && (variant == 0 || variant == 20);
+        const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked;
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
             if (count) hipLaunchKernelGGL((k_closest_hit_q<true>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
@@ -467,7 +472,9 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
         if (p->n_lights && !fused) {
-            if (count)             hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
+                                                      s->dev, fp, o_hit, o_t, s->ws_shadow, ctr, L_CHUNK);
+            else if (count)        hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);

@@ -534,6 +534,57 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
 
+// Background tiles: most of a typical frame, and a wave that only learns that its 16 rays miss every object costs ~150 VALU
+// instructions of set-up, queueing and write-out.  So wave 0 of a workgroup first puts the tile's 64 rays (one per lane)
+// through the slab test of every object's root box -- the very test the first node step of each ray would run -- while the
+// other three waves wait at a launch-time barrier (nobody has work to wait behind yet); if no ray passes any root it writes
+// the 64 background pixels (and, when shadow_bits is given, the tile's all-clear shadow words) with full lanes.  Returns true
+// to every thread of the workgroup when the tile is finished.
+template <bool FILTER>
+__device__ __forceinline__ bool finish_background_tile(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                       float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                       unsigned long long* __restrict__ shadow_bits) {
+    __shared__ uint32_t tile_live;
+    if ((threadIdx.x >> 6) == 0) {
+        const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
+        const uint32_t px = blockIdx.x * 8 + (quad & 1) * 4 + (ql & 3), r = blockIdx.y * 8 + (quad >> 1) * 4 + (ql >> 2);
+        const bool live = px < p.W && r < p.rows;
+        const V3 o = mk(0.f, 0.f, 0.f);
+        const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
+        const RayRcp rc = ray_rcp(dd);
+        const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+        bool any = false;
+        for (uint32_t ob = 0; ob < s.n_objects; ob++) {
+            const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
+            const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+            bool pass;
+            if (FILTER) {
+                bool amb;
+                pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+            } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+            any |= pass;
+        }
+        const unsigned long long m = __ballot(live && any);
+        if (lane == 0) tile_live = m != 0ull;
+        if (m == 0ull) {
+            if (live) {      // what closest_hit_phase writes for a miss (:518, drawImage:476-487)
+                const size_t pix = (size_t)r * p.W + px;
+                hit_id[pix] = -1;
+                t_out[pix] = __builtin_inff();
+                if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+                if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+            }
+            if (shadow_bits) {
+                const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                for (uint32_t l = lane; l < p.n_lights; l += 64) shadow_bits[tile_index * p.n_lights + l] = 0ull;
+            }
+        }
+    }
+    __syncthreads();
+    return tile_live == 0u;
+}
+
 template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
 __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
@@ -545,6 +596,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ float4 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
+    if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr)) return;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                       hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
 }
@@ -687,8 +739,10 @@ template <bool SEQ, int NQCAP, bool FILTER, int RS>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds<RS>& L,
                                              int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
-                                             const uint32_t bx, const uint32_t by, const uint32_t gx, const uint32_t wave) {
+                                             const uint32_t bx, const uint32_t by, const uint32_t gx, const uint32_t wave,
+                                             const uint32_t l_begin = 0u, const uint32_t l_end_ = 0xffffffffu) {   // light samples [l_begin, l_end) of p.n_lights
     const uint32_t lane = threadIdx.x & 63;
+    const uint32_t l_end = l_end_ < p.n_lights ? l_end_ : p.n_lights;
     float4* ray = L.ray;
     int2* selfr = L.selfr;
     uint32_t* flag = L.flag;
@@ -752,8 +806,8 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
 
     constexpr uint32_t OBJ_G = (NQCAP / (2 * RS)) < 16 ? (NQCAP / (2 * RS)) : 16;     // RS * OBJ_G <= NQCAP / 2
     const uint32_t n_obj = s.n_objects;
-    for (uint32_t l0 = 0; l0 < p.n_lights; l0 += 64) {               // light samples in groups of 64
-        const uint32_t Lg = (p.n_lights - l0) < 64u ? (p.n_lights - l0) : 64u;
+    for (uint32_t l0 = l_begin; l0 < l_end; l0 += 64) {              // light samples in groups of 64
+        const uint32_t Lg = (l_end - l0) < 64u ? (l_end - l0) : 64u;
         L.mask[lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_items = nh * Lg;
@@ -881,19 +935,23 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
 }
 
-template <bool SEQ, int NQCAP, bool FILTER>
+// blockIdx.z = chunk of `l_chunk` light samples: with many samples a tile's shadow rays are cut over several workgroups (a
+// wave that walks 16 pixels x 64 samples through dense geometry alone can outlast the rest of the launch)
+template <bool SEQ, int NQCAP, bool FILTER, int RS = 16>
 __global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                    const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
-                                                   unsigned long long* __restrict__ counters) {
+                                                   unsigned long long* __restrict__ counters, uint32_t l_chunk = 0xffffffffu) {
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
-    __shared__ ShadowLds<16> lds_all[4];
+    __shared__ ShadowLds<RS> lds_all[4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
-    shadow_phase<SEQ, NQCAP, FILTER, 16>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave);
+    const uint32_t l_begin = l_chunk == 0xffffffffu ? 0u : blockIdx.z * l_chunk;
+    shadow_phase<SEQ, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave,
+                                         l_begin, l_chunk == 0xffffffffu ? 0xffffffffu : l_begin + l_chunk);
 }
 
 // =================================================================================================
@@ -914,50 +972,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
     int32_t id; float t; V3 d;
     unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
     SRT_STAMP(k0);
-    if (!COUNT) {
-        // Background tiles: most of a typical frame, and a wave that only learns that its 16 rays miss every object costs
-        // ~150 VALU instructions of set-up, queueing and write-out.  So wave 0 first puts the tile's 64 rays (one per lane)
-        // through the slab test of every object's root box -- the very test the first node step of each ray would run --
-        // while the other three waves wait at the launch-time barrier; if no ray passes any root, it writes the 64
-        // background pixels and the tile's (all-clear) shadow words with full lanes and the workgroup is done.
-        __shared__ uint32_t tile_live;
-        if (wave == 0) {
-            const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
-            const uint32_t px = blockIdx.x * 8 + (quad & 1) * 4 + (ql & 3), r = blockIdx.y * 8 + (quad >> 1) * 4 + (ql >> 2);
-            const bool live = px < p.W && r < p.rows;
-            const V3 o = mk(0.f, 0.f, 0.f);
-            const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
-            const RayRcp rc = ray_rcp(dd);
-            const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
-            bool any = false;
-            for (uint32_t ob = 0; ob < s.n_objects; ob++) {
-                const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
-                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
-                bool pass;
-                if (FILTER) {
-                    bool amb;
-                    pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
-                    if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-                } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-                any |= pass;
-            }
-            const unsigned long long m = __ballot(live && any);
-            if (lane == 0) tile_live = m != 0ull;
-            if (m == 0ull) {
-                if (live) {      // what closest_hit_phase writes for a miss (:518, drawImage:476-487)
-                    const size_t pix = (size_t)r * p.W + px;
-                    hit_id[pix] = -1;
-                    t_out[pix] = __builtin_inff();
-                    if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
-                    if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
-                }
-                const size_t tile_index = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-                for (uint32_t l = lane; l < p.n_lights; l += 64) shadow_bits[tile_index * p.n_lights + l] = 0ull;
-            }
-        }
-        __syncthreads();                 // at launch: nobody has work to wait behind yet
-        if (!tile_live) return;
-    }
+    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits)) return;
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
     __builtin_amdgcn_wave_barrier();

@@ -465,7 +465,8 @@ def test_adversarial_scenes_match_oracle(srt, oracle, seed):
 def test_many_objects_and_light_groups(srt, oracle, n_obj, L):
     """Object loops run in groups (roots of up to 16 objects are queued at once, 4 with 64 shadow rays in flight) and light
     samples in groups of 64: scenes with more objects / samples than one group, through the shipped kernels (16 shadow rays
-    per round below 8 samples, 64 from 8 on) and the counting build, against the oracle."""
+    per round in the fused kernel below 8 samples; from 8 on two launches with the samples cut into chunks over
+    blockIdx.z) and the counting build, against the oracle."""
     from simple_raytracer_amd import host
     import scenes
     rng = np.random.default_rng(100 + n_obj + L)
@@ -488,7 +489,7 @@ def test_many_objects_and_light_groups(srt, oracle, n_obj, L):
     lights = abi.light_staircase(recipe.light, L)
     c = oracle.render(flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
     assert (c["hit_id"] >= 0).sum() > 300
-    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8):          # shipped fused, counting build, unfused
+    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8, 17 << 8):   # shipped (fused below 8 samples, else chunked), counting build, unfused, fused with 64 rays in flight
         o = ds.render(abi.make_params(W, H, lights, flags=flags))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
