@@ -18,6 +18,8 @@ for variant in (0,):
     for _ in range(3):
         o = ds.render(p)
     d = o["rgb_linear"].reshape(-1).view(np.uint64)[: n_waves * 8].reshape(n_waves, 8)
+    ok = (d[:, 6] > 0) & (d[:, 7] > d[:, 6])          # waves of background tiles leave no record (they end at the launch-time barrier)
+    d = d[ok]
     closest = d[:, 0].astype(np.float64)
     hw = d[:, 5]
     k0 = d[:, 6].astype(np.int64); k1 = d[:, 7].astype(np.int64)
