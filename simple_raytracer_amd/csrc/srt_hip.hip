@@ -472,7 +472,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
         if (p->n_lights && !fused) {
-            if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
+            if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64, 6>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
                                                       s->dev, fp, o_hit, o_t, s->ws_shadow, ctr, L_CHUNK);
             else if (count)        hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);

@@ -937,8 +937,8 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
 
 // blockIdx.z = chunk of `l_chunk` light samples: with many samples a tile's shadow rays are cut over several workgroups (a
 // wave that walks 16 pixels x 64 samples through dense geometry alone can outlast the rest of the launch)
-template <bool SEQ, int NQCAP, bool FILTER, int RS = 16>
-__global__ __launch_bounds__(256) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+template <bool SEQ, int NQCAP, bool FILTER, int RS = 16, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                    const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
                                                    unsigned long long* __restrict__ counters, uint32_t l_chunk = 0xffffffffu) {
     __shared__ uint32_t nq_all[4][NQCAP];
