@@ -386,6 +386,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     if ((p->flags & SRT_FLAG_SMOOTH_NORMALS) && (!s->dev.tri_normals || variant_of(p) == 1)) return SRT_ERR_ARG;   // needs vertex normals
     DevParams dp;
     dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
+    dp.xcd_rows = (s->bytes > (32ull << 20) || variant_of(p) == 18) ? 1u : 0u;       // records far beyond one XCD's 4 MiB L2 (variant 18: forced, for the tests)
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
     dp.i0 = (int)(-(float)p->width / 2); dp.j0 = (int)(-(float)p->height / 2);       // :511,513
@@ -445,7 +446,8 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
         // launch (K4 shape: 3.9 -> 2.5 ms per frame; K3 with 16 samples: 0.89 -> 0.64 ms); below 8 the fused kernel wins.
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
         const bool chunked = p->n_lights >= 8 && !count && (variant == 0 || variant == 20);
-        const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked;
+        const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked;     // (variants 11, 17, 18 are configurations of the fused kernel)
+        const dim3 grid8x(grid8.x, fp.xcd_rows ? (grid8.y + 7) / 8 * 8 : grid8.y);      // whole tile rows per XCD: y padded to 8 rows
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
             if (count) hipLaunchKernelGGL((k_closest_hit_q<true>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
@@ -462,6 +464,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 17 || (variant == 0 && p->n_lights >= 8))      // many light samples: 64 shadow rays in flight per wave
                                         hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);

@@ -190,7 +190,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 18])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -489,7 +489,7 @@ def test_many_objects_and_light_groups(srt, oracle, n_obj, L):
     lights = abi.light_staircase(recipe.light, L)
     c = oracle.render(flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
     assert (c["hit_id"] >= 0).sum() > 300
-    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8, 17 << 8):   # shipped (fused below 8 samples, else chunked), counting build, unfused, fused with 64 rays in flight
+    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8, 17 << 8, 18 << 8):   # shipped (fused below 8 samples, else chunked), counting build, unfused, fused with 64 rays in flight
         o = ds.render(abi.make_params(W, H, lights, flags=flags))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
