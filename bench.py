@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 NODE_BYTES, TRI_BYTES = 32, 36  # algorithmic bytes per slab test / Moller-Trumbore test
-BLOCK_ROWS = 16                 # scanline block size for the multi-GPU block-cyclic split
+BLOCK_ROWS = 8                  # scanline block size for the multi-GPU block-cyclic split
 
 
 def main():
