@@ -33,8 +33,10 @@ enum {
     SRT_ERR_DEVICE      = 3,   /* HIP runtime error (srt_last_hip_error() has the hipError_t)       */
     SRT_ERR_NO_GPU      = 4,   /* no HIP device visible: the product path never falls back to CPU   */
     SRT_ERR_TEXTURE     = 5,   /* triangle references a texture id >= n_textures                    */
-    SRT_ERR_LIMIT       = 6    /* size exceeds an implementation limit (n_tris < 2^27, ...)          */
+    SRT_ERR_LIMIT       = 6,   /* size exceeds an implementation limit (n_tris < 2^26, n_nodes < 2^26) */
+    SRT_ERR_OOM         = 7    /* host allocation failed (std::bad_alloc caught at the boundary)    */
 };
+/* No entry point lets a C++ exception escape: bad_alloc -> SRT_ERR_OOM, anything else -> SRT_ERR_DEVICE. */
 
 /* ---- flat scene: what the host hands over once per frame ---------------------------------------
  * It is the reference's ObjectManager state (Object.h:59-89) with the string-keyed maps and Node*
@@ -187,6 +189,10 @@ int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb);
 int srt_kat_interp_normal(int device, uint32_t n, const float* in12 /* 3 normals + barycentrics */, float* out3);   /* interpolateNormal :132-140 */
 int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* fast, float* lib);   /* the device powf: shipped form vs (float)pow(double) */
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q);
+
+/* Test hook: the next n host allocations made on behalf of a caller fail (std::bad_alloc inside the library), so that
+ * the SRT_ERR_OOM path can be exercised without exhausting memory.  Not for production use. */
+void srt_debug_fail_host_allocs(int n);
 
 const char* srt_strerror(int code);
 int         srt_last_hip_error(void);

@@ -11,6 +11,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 SRT_OK = 0
+SRT_ERR_ARG, SRT_ERR_LAYOUT, SRT_ERR_DEVICE, SRT_ERR_NO_GPU, SRT_ERR_TEXTURE, SRT_ERR_LIMIT, SRT_ERR_OOM = 1, 2, 3, 4, 5, 6, 7
 SRT_FLAG_SMOOTH_NORMALS = 1 << 0
 SRT_FLAG_COUNT_WORK = 1 << 1
 SRT_FLAG_NO_TIMING = 1 << 2

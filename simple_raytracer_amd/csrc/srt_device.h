@@ -45,6 +45,7 @@ struct __attribute__((aligned(16))) DevTriO {
 static_assert(sizeof(DevTriO) == 48, "origin-ray triangle record is 48 B");
 
 constexpr int LEAF_SHIFT = 5;
+constexpr int NODE_INDEX_BITS = 26;      // a node-queue entry is (node index << 6 | ray lane) in 32 bits
 constexpr int LEAF_MAX = (1 << LEAF_SHIFT) - 1;
 
 struct V3 { float x, y, z; };

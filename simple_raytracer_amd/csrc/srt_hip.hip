@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <thread>
 #include <vector>
@@ -31,6 +32,22 @@ static thread_local int g_last_hip = 0;
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return SRT_ERR_DEVICE; } \
     } while (0)
 
+// No C++ exception may cross the extern "C" boundary ("never throws"): every entry point that allocates
+// or spawns threads runs its body through guarded().
+template <typename F>
+static int guarded(F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return SRT_ERR_OOM; }
+    catch (...) { return SRT_ERR_DEVICE; }
+}
+// Test hook (srt_debug_fail_host_allocs): the next n guarded host allocations throw std::bad_alloc.
+static std::atomic<int> g_fail_allocs{0};
+static inline void alloc_gate() {
+    int n = g_fail_allocs.load(std::memory_order_relaxed);
+    while (n > 0 && !g_fail_allocs.compare_exchange_weak(n, n - 1)) {}
+    if (n > 0) throw std::bad_alloc();
+}
+
 constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
 
 struct srt_scene {
@@ -45,6 +62,7 @@ struct srt_scene {
     unsigned long long* d_counters = nullptr; unsigned long long* h_counters = nullptr;   // device: two sets used alternately
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
+    bool ctr_dirty = false;                       // a render returned an error after its first launch
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
     float* ws_acc = nullptr; float* ws_sub = nullptr; int32_t* ws_sub_hit = nullptr; float* ws_sub_t = nullptr; size_t ws_acc_pixels = 0;
     int n_cu = 256;
@@ -111,6 +129,7 @@ const char* srt_strerror(int code) {
     case SRT_ERR_NO_GPU: return "no HIP device: this library has no CPU fallback";
     case SRT_ERR_TEXTURE: return "triangle references a texture that does not exist";
     case SRT_ERR_LIMIT: return "size exceeds an implementation limit";
+    case SRT_ERR_OOM: return "out of host memory";
     default: return "unknown error";
     }
 }
@@ -236,22 +255,22 @@ static int build_device_records(const srt_scene_desc* d, std::vector<DevNode>& n
     return SRT_OK;
 }
 
-int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
+static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** out) {
     if (!d || !out) return SRT_ERR_ARG;
     *out = nullptr;
     if (!d->n_objects || !d->n_nodes || !d->node_min || !d->node_max || !d->node_left || !d->node_right ||
         !d->node_first || !d->node_count || !d->obj_root || !d->obj_color || !d->obj_material) return SRT_ERR_ARG;
     if (d->n_tris && (!d->tri_points || !d->tri_obj)) return SRT_ERR_ARG;
-    if (d->n_tris >= (1u << (31 - LEAF_SHIFT)) || d->n_nodes >= (1u << 30)) return SRT_ERR_LIMIT;
+    // queue entries of the node-queue kernels pack (node << 6 | ray lane) into 32 bits; a leaf word packs (first << 5 | count)
+    static_assert(NODE_INDEX_BITS + 6 == 32, "node-queue entry = node index + 6-bit lane");
+    if (d->n_tris >= (1u << (31 - LEAF_SHIFT)) || d->n_nodes >= (1u << NODE_INDEX_BITS)) return SRT_ERR_LIMIT;
     if (d->n_textures && (!d->tex_rgb || !d->tex_off || !d->tex_w || !d->tex_h || !d->tri_tex || !d->tri_texcoord)) return SRT_ERR_ARG;
     for (uint32_t i = 0; i < d->n_tris; i++) {
         if (d->tri_obj[i] < 0 || (uint32_t)d->tri_obj[i] >= d->n_objects) return SRT_ERR_LAYOUT;
         if (d->tri_tex && d->tri_tex[i] >= (int32_t)d->n_textures) return SRT_ERR_TEXTURE;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SRT_ERR_NO_GPU;
-    if (device < 0 || device >= ndev) return SRT_ERR_ARG;
-
+    // host-side records first (validates the layout contract; pure CPU work), then the device
+    alloc_gate();
     std::vector<DevNode> nodes; std::vector<int2> ranges;
     int rc = build_device_records(d, nodes, ranges);
     if (rc != SRT_OK) return rc;
@@ -275,9 +294,12 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
         }
     }
 
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SRT_ERR_NO_GPU;
+    if (device < 0 || device >= ndev) return SRT_ERR_ARG;
     HIP_TRY(hipSetDevice(device));
     srt_scene* s = new (std::nothrow) srt_scene();
-    if (!s) return SRT_ERR_ARG;
+    if (!s) return SRT_ERR_OOM;
     s->device = device;
     #define UP(expr) do { rc = (expr); if (rc != SRT_OK) { srt_scene_destroy(s); return rc; } } while (0)
     UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
@@ -319,6 +341,12 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     return SRT_OK;
 }
 
+int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
+    return guarded([&] { return scene_create_impl(device, d, out); });
+}
+
+void srt_debug_fail_host_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
+
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
 
 static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) & 0xffu; }
@@ -333,18 +361,23 @@ static int check_params(const srt_params* p) {
     return SRT_OK;
 }
 
-int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t* d_hit_id, float* d_t,
-                      float* d_rgb_linear, uint8_t* d_rgb8) {
+static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, int32_t* d_hit_id, float* d_t,
+                              float* d_rgb_linear, uint8_t* d_rgb8) {
     if (!s) return SRT_ERR_ARG;
     int rc = check_params(p);
     if (rc != SRT_OK) return rc;
+    // every argument check comes before any state of the handle changes (counter sets, pending work)
+    if ((p->flags & SRT_FLAG_SMOOTH_NORMALS) && (!s->dev.tri_normals || variant_of(p) == 1)) return SRT_ERR_ARG;   // needs vertex normals
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t rows = srt_rows_owned(p);
+    if (!rows) {                              // nothing to launch; work of an earlier render stays pending
+        if (!s->pending) std::memset(&s->last, 0, sizeof(s->last));
+        return SRT_OK;
+    }
     std::memset(&s->last, 0, sizeof(s->last));
     s->last.rows = rows;
     s->last.primary_rays = (uint64_t)p->width * rows;
-    if (!rows) { s->pending = false; return SRT_OK; }
     const size_t pixels = (size_t)p->width * rows;
     // workspace for hit ids / t when the caller does not want them (the shade kernel does)
     if ((!d_hit_id || !d_t) && s->ws_pixels < pixels) {
@@ -378,12 +411,12 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     // render will use, so no memset or copy is enqueued per frame; srt_sync reads the last set.
     unsigned long long* ctr = s->d_counters + (s->render_seq & 1) * NCTR;
     unsigned long long* ctr_next = s->d_counters + ((s->render_seq + 1) & 1) * NCTR;
-    s->render_seq++;
-    s->d_ctr_last = ctr;
+    // a render that failed half-way may have left either set dirty: clear both before the next one
+    if (s->ctr_dirty) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long), stream));
+    s->ctr_dirty = true;
     // a counting run must not inherit whatever replayed graphs left in the set (their frames use fixed sets)
     if (p->flags & SRT_FLAG_COUNT_WORK) HIP_TRY(hipMemsetAsync(ctr, 0, NCTR * sizeof(unsigned long long), stream));
 
-    if ((p->flags & SRT_FLAG_SMOOTH_NORMALS) && (!s->dev.tri_normals || variant_of(p) == 1)) return SRT_ERR_ARG;   // needs vertex normals
     DevParams dp;
     dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
     dp.xcd_rows = (s->bytes > (32ull << 20) || variant_of(p) == 18) ? 1u : 0u;       // records far beyond one XCD's 4 MiB L2 (variant 18: forced, for the tests)
@@ -524,11 +557,18 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream_, int32_t*
     } else {
         s->last_done = nullptr;
     }
+    s->render_seq++;                          // the sets only swap once every launch of this render is enqueued
+    s->d_ctr_last = ctr;
+    s->ctr_dirty = false;
     s->last_stream = stream;
     s->pending = true;
     s->last.primary_rays = (uint64_t)p->width * rows * spp;
     s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
     return SRT_OK;
+}
+
+int srt_render_device(srt_scene* s, const srt_params* p, void* stream, int32_t* d_hit_id, float* d_t, float* d_rgb_linear, uint8_t* d_rgb8) {
+    return guarded([&] { return render_device_impl(s, p, stream, d_hit_id, d_t, d_rgb_linear, d_rgb8); });
 }
 
 int srt_sync(srt_scene* s, srt_stats* stats) {
@@ -626,6 +666,7 @@ int srt_kat_ray_aabb(int device, uint32_t n, const float* ray_od, const float* b
 
 int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const float* tri_points, float* t) {
     if (!n || !ray_od || !tri_points || !t) return SRT_ERR_ARG;
+    return guarded([&]() -> int {
     HIP_TRY(hipSetDevice(device));
     std::vector<DevTri> tris(n);
     for (uint32_t i = 0; i < n; i++) tris[i] = derive_triangle(tri_points + 12 * (size_t)i);
@@ -634,10 +675,12 @@ int srt_kat_ray_triangle(int device, uint32_t n, const float* ray_od, const floa
     hipLaunchKernelGGL(k_kat_ray_triangle, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)r.p, (const DevTri*)q.p, (float*)o.p);
     HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     return o.down(t, (size_t)n * 4);
+    });
 }
 
 int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb) {
     if (!n || !in28 || !rgb) return SRT_ERR_ARG;
+    return guarded([&]() -> int {
     HIP_TRY(hipSetDevice(device));
     std::vector<DevTri> tris(n);
     for (uint32_t i = 0; i < n; i++) tris[i] = derive_triangle(in28 + 28 * (size_t)i + 6);
@@ -646,6 +689,7 @@ int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb) {
     hipLaunchKernelGGL(k_kat_phong, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)a.p, (const DevTri*)q.p, (float*)o.p);
     HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     return o.down(rgb, (size_t)n * 12);
+    });
 }
 
 int srt_kat_interp_normal(int device, uint32_t n, const float* in12, float* out3) {

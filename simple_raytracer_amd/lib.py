@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 # every symbol include/srt.h declares
 ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_scene_create", "srt_scene_destroy",
                "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
-               "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow")
+               "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
+               "srt_debug_fail_host_allocs")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -62,6 +63,8 @@ def load():
         L.srt_strerror.restype = C.c_char_p
         L.srt_last_hip_error.restype = C.c_int
         L.srt_abi_version.restype = C.c_uint32
+        L.srt_debug_fail_host_allocs.argtypes = [C.c_int]
+        L.srt_debug_fail_host_allocs.restype = None
         L.srt_kat_ray_aabb.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _u8p, _u8p, _u8p, _u8p]
         L.srt_kat_ray_triangle.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p, _f32p]
         L.srt_kat_phong.argtypes = [C.c_int, C.c_uint32, _f32p, _f32p]

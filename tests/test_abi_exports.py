@@ -55,6 +55,26 @@ def test_argument_errors_without_device_work(L):
     assert b"argument" in L.srt_strerror(1) and b"fallback" in L.srt_strerror(4)
 
 
+def test_no_exception_crosses_the_c_abi(L):
+    """the ABI never throws.  A host allocation failure inside srt_scene_create (forced by the test hook)
+    comes back as SRT_ERR_OOM; the same call without the hook gets as far as the device check."""
+    import golden_util as gu
+    g = gu.GoldenScene("cube")
+    d = g.flat.desc()
+    h = C.c_void_p()
+    L.srt_debug_fail_host_allocs(1)
+    assert L.srt_scene_create(0, C.byref(d), C.byref(h)) == abi.SRT_ERR_OOM and not h.value
+    assert b"memory" in L.srt_strerror(abi.SRT_ERR_OOM)
+    L.srt_debug_fail_host_allocs(0)
+    rc = L.srt_scene_create(0, C.byref(d), C.byref(h))
+    assert rc in (abi.SRT_OK, abi.SRT_ERR_NO_GPU)
+    if rc == abi.SRT_OK:
+        L.srt_scene_destroy(h)
+    # limits are checked before anything is allocated: 2^26 nodes do not fit a node-queue entry
+    d2 = g.flat.desc(); d2.n_nodes = 1 << 26
+    assert L.srt_scene_create(0, C.byref(d2), C.byref(h)) == abi.SRT_ERR_LIMIT
+
+
 def test_product_does_not_link_the_oracle():
     """The product library must not route through oracle/ (parity claims depend on it)."""
     import subprocess
