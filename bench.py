@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=36, help="frames rendered per step (the reference renders a 36-frame orbit per run)")
-    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground", "main_nocats", "soup"])
+    ap.add_argument("--workload", default="ground_bunny", choices=["ground_bunny", "cube_ground", "main_nocats", "k4", "soup"])
     ap.add_argument("--tris", type=int, default=1000000, help="triangle count of the synthetic soup workload (BASELINE.json configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -259,6 +259,8 @@ def main():
                        else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
                              else f"main_nocats: the scene of the reference's main() (ground cube, bunny, 3 textured trees; the cats are a missing blob), "
                                   f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[3] shape]" if args.workload == "main_nocats"
+                             else f"k4: composite scene (ground cube, bunny, 3 textured trees, horse, house without its 'Plane'; 223,855 triangles, 8 textures), "
+                                  f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[3]]" if args.workload == "k4"
                              else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s), spp {args.spp} [BASELINE.json configs[4]]"),
                        "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
                                 f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",

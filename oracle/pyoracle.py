@@ -239,6 +239,17 @@ class RefScene:
         self.L.ref_om_add_texture(self.om, texname.encode(), C.c_int32(tex.shape[1]), C.c_int32(tex.shape[0]), _p(tex, _u8p))
         self.L.ref_om_add_textured_object(self.om, name.encode(), C.c_uint32(pts.shape[0]), _p(pts, _f32p), _p(tc, _f32p), texname.encode())
 
+    def add_multi_textured_object(self, name, points, texcoord, tri_tex, tex_names, textures):
+        """Object whose triangles use several textures (house.obj): tri_tex[i] indexes tex_names / textures, -1 = untextured."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 12)
+        tc = np.ascontiguousarray(texcoord, np.float32).reshape(-1, 6)
+        tt = np.ascontiguousarray(tri_tex, np.int32)
+        for nm, tex in zip(tex_names, textures):
+            tex = np.ascontiguousarray(tex, np.uint8)
+            self.L.ref_om_add_texture(self.om, nm.encode(), C.c_int32(tex.shape[1]), C.c_int32(tex.shape[0]), _p(tex, _u8p))
+        self.L.ref_om_add_multi_textured_object(self.om, name.encode(), C.c_uint32(pts.shape[0]), _p(pts, _f32p), _p(tc, _f32p), _p(tt, _i32p),
+                                                "\n".join(tex_names).encode())
+
     def clone(self, src, dst): self.L.ref_om_clone(self.om, src.encode(), dst.encode())
     def set_color(self, name, rgb): self.L.ref_om_set_color(self.om, name.encode(), *[float(x) for x in rgb])
     def set_props(self, name, p): self.L.ref_om_set_props(self.om, name.encode(), *[float(x) for x in p])
@@ -296,23 +307,20 @@ class RefScene:
                              _p(a["tri_points"], _f32p), _p(a["tri_texcoord"], _f32p), _p(a["tri_color"], _f32p),
                              _p(a["tri_obj"], _i32p), _p(a["tri_has_tex"], _i32p))
         names = self.object_order()
+        # texture ids: distinct loaded texture names in order of first use over the flat triangle sequence (the harness walks
+        # the reference's trees; `textures`, the per-object map older callers pass, is only cross-checked)
         tri_tex = np.full(nt, -1, np.int32)
+        buf = C.create_string_buffer(1 << 16)
+        self.L.ref_om_export_textures(self.om, _p(tri_tex, _i32p), buf, C.c_uint32(1 << 16))
+        tex_names = [x for x in buf.value.decode().split("\n") if x]
         tex_kw = {}
-        if a["tri_has_tex"].any():
-            # texture ids: per object, the textureName of each triangle, looked up in leaf order via
-            # the per-object loader arrays is not possible after the BVH sort, so resolve by name here.
-            assert textures is not None, "textured scene: pass textures={object name: texture name}"
-            tex_names, rgbs = [], []
-            for k, nm in enumerate(names):
-                tn = textures.get(nm)
-                if tn is None:
-                    continue
-                if tn not in tex_names:
-                    img = self.texture(tn)
-                    assert img is not None, f"texture {tn} not loaded by the reference"
-                    tex_names.append(tn); rgbs.append(img)
-                sel = (a["tri_obj"] == k) & (a["tri_has_tex"] != 0)
-                tri_tex[sel] = tex_names.index(tn)
+        if tex_names:
+            if textures is not None:
+                for k, nm in enumerate(names):
+                    if nm in textures:
+                        sel = (a["tri_obj"] == k) & (a["tri_has_tex"] != 0)
+                        assert np.all(tri_tex[sel] == tex_names.index(textures[nm])), nm
+            rgbs = [self.texture(tn) for tn in tex_names]
             offs = np.cumsum([0] + [r.size for r in rgbs[:-1]]).astype(np.uint64)
             tex_kw = dict(tex_rgb=np.concatenate([r.reshape(-1) for r in rgbs]), tex_off=offs,
                           tex_w=np.array([r.shape[1] for r in rgbs], np.uint32), tex_h=np.array([r.shape[0] for r in rgbs], np.uint32))
@@ -342,14 +350,16 @@ class RefScene:
             raise RuntimeError("adapter: " + err.value.decode())
         return rgb, int(n)
 
-    def trace(self, W, H, light3, n_lights):
-        """Closest-hit ids / t / softShadow(n_lights) / pre-tone-map sums via the reference's leaf functions."""
+    def trace(self, W, H, light3, n_lights, rows=None):
+        """Closest-hit ids / t / softShadow(n_lights) / pre-tone-map sums via the reference's leaf functions.  rows = (y0, y1):
+        only that band of the W x H frame is traced and returned."""
         light3 = np.ascontiguousarray(light3, np.float32)
-        hit = np.empty((H, W), np.int32); t = np.empty((H, W), np.float32)
-        tone = np.empty((H, W, 3), np.float32); lin = np.empty((H, W, 3), np.float32)
-        self.L.ref_trace(self.om, C.c_uint32(W), C.c_uint32(H), _p(light3, _f32p), C.c_int(n_lights),
-                         _p(hit, _i32p), _p(t, _f32p), _p(tone, _f32p), _p(lin, _f32p))
-        return hit, t, tone, lin
+        y0, y1 = rows if rows is not None else (0, H)
+        hit = np.full((H, W), -1, np.int32); t = np.zeros((H, W), np.float32)
+        tone = np.zeros((H, W, 3), np.float32); lin = np.zeros((H, W, 3), np.float32)
+        self.L.ref_trace_rows(self.om, C.c_uint32(W), C.c_uint32(H), C.c_uint32(y0), C.c_uint32(y1), _p(light3, _f32p), C.c_int(n_lights),
+                              _p(hit, _i32p), _p(t, _f32p), _p(tone, _f32p), _p(lin, _f32p))
+        return hit[y0:y1], t[y0:y1], tone[y0:y1], lin[y0:y1]
 
 
 def ref_kat_ray_triangle(ray_od, tri):

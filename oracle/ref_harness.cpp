@@ -126,6 +126,25 @@ void ref_om_add_textured_object(void* om_, const char* name, uint32_t n, const f
     }
 }
 
+// Array-fed object with several textures (house.obj: six materials with their own map_Kd): per triangle an index into
+// `names` (newline-separated; -1 = untextured triangle, textureName stays empty as the loader leaves it when the material has no
+// diffuse map, Object.cpp:98-102,149).  The textures themselves are added with ref_om_add_texture.
+void ref_om_add_multi_textured_object(void* om_, const char* name, uint32_t n, const float* points, const float* texcoord /* n x 6 */,
+                                      const int32_t* tri_tex /* n */, const char* names) {
+    ObjectManager* om = (ObjectManager*)om_;
+    ref_om_add_object(om_, name, n, points);
+    std::vector<std::string> list;
+    for (const char* p = names; *p;) { const char* e = std::strchr(p, '\n'); if (!e) e = p + std::strlen(p); list.emplace_back(p, e); p = *e ? e + 1 : e; }
+    std::vector<Triangle>& tris = om->objTriangles[name];
+    for (uint32_t i = 0; i < n; i++) {
+        if (tri_tex[i] < 0) continue;
+        tris[i].colorOneCoordinate = glm::vec2(texcoord[i*6], texcoord[i*6+1]);
+        tris[i].colorTwoCoordinate = glm::vec2(texcoord[i*6+2], texcoord[i*6+3]);
+        tris[i].colorThreeCoordinate = glm::vec2(texcoord[i*6+4], texcoord[i*6+5]);
+        tris[i].textureName = list.at((size_t)tri_tex[i]);
+    }
+}
+
 // Clone as main() does it (simple_raytracer.cpp:565,597,644): triangles only; colour/material are
 // whatever unordered_map::operator[] default-inserts later unless set explicitly.
 void ref_om_clone(void* om_, const char* src, const char* dst) {
@@ -225,6 +244,39 @@ void ref_om_export(void* om_, uint32_t* obj_root /* n_objects */, float* obj_col
     }
 }
 
+// Texture ids of the exported triangles (same walk as ref_om_export): index into the list of distinct LOADED texture names in
+// order of first use over the flat triangle sequence, -1 for untextured triangles (and for a textureName whose image failed to
+// load -- the reference would null-deref on such a hit, simple_raytracer.cpp:354-358; scenes used for goldens contain none).
+// Writes the names newline-separated; returns how many.
+namespace {
+void tex_walk(const Node* n, ObjectManager* om, std::vector<std::string>& names, int32_t* tri_tex, uint32_t& cursor) {
+    if (!n->left && !n->right) {
+        for (const Triangle& t : n->triangles) {
+            int32_t id = -1;
+            if (!t.textureName.empty() && om->textureData.count(t.textureName)) {
+                size_t k = 0;
+                while (k < names.size() && names[k] != t.textureName) k++;
+                if (k == names.size()) names.push_back(t.textureName);
+                id = (int32_t)k;
+            }
+            tri_tex[cursor++] = id;
+        }
+        return;
+    }
+    tex_walk(n->left, om, names, tri_tex, cursor);
+    tex_walk(n->right, om, names, tri_tex, cursor);
+}
+}
+uint32_t ref_om_export_textures(void* om_, int32_t* tri_tex /* n_tris */, char* buf, uint32_t cap) {
+    ObjectManager* om = (ObjectManager*)om_;
+    std::vector<std::string> names; uint32_t cursor = 0;
+    for (const auto& p : om->objTriangles) tex_walk(om->boundingVolumeHierarchy[p.first], om, names, tri_tex, cursor);
+    std::string s;
+    for (const std::string& nm : names) { s += nm; s += '\n'; }
+    if (cap) { std::strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return (uint32_t)names.size();
+}
+
 // ---- the hot path itself --------------------------------------------------------------------
 // sendRaysAndIntersectPointsColors (simple_raytracer.cpp:505-525), result scattered to a dense
 // W x H x 3 float image (row-major, y down), zero where the reference emitted nothing.
@@ -244,8 +296,16 @@ uint32_t ref_render(void* om, uint32_t W, uint32_t H, const float* light4, float
 // for an arbitrary lightAmount.  Requires ref_om_export() to have tagged the leaves.
 //   hit_id[H*W] canonical id or -1;  t[H*W];  tone[H*W*3] = softShadow(lightAmount,...) result;
 //   lin[H*W*3] = pre-tone-map sum rebuilt from shadowIntersection + phongIllumination (:366-383).
+//   rows [y0, y1) of the W x H frame only (outputs stay full-frame arrays; other rows are not written): a 3840x2160 frame with
+//   64 light samples is hours of reference time, a band of scanlines is minutes.
+void ref_trace_rows(void* om_, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, const float* light3, int lightAmount,
+                    int32_t* hit_id, float* t_out, float* tone, float* lin);
 void ref_trace(void* om_, uint32_t W, uint32_t H, const float* light3, int lightAmount,
                int32_t* hit_id, float* t_out, float* tone, float* lin) {
+    ref_trace_rows(om_, W, H, 0, H, light3, lightAmount, hit_id, t_out, tone, lin);
+}
+void ref_trace_rows(void* om_, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, const float* light3, int lightAmount,
+                    int32_t* hit_id, float* t_out, float* tone, float* lin) {
     ObjectManager* om = (ObjectManager*)om_;
     glm::vec3 lightPos(light3[0], light3[1], light3[2]);
     glm::vec3 lightColor(1.0f, 1.0f, 1.0f);
@@ -255,6 +315,7 @@ void ref_trace(void* om_, uint32_t W, uint32_t H, const float* light3, int light
         for (int j = -imageSize.y / 2; j < imageSize.y / 2; ++j) {
             ray.direction.x = i + 0.0f; ray.direction.y = j + 0.0f;
             int px = i + imageSize.x / 2, py = j + imageSize.y / 2;
+            if ((uint32_t)py < y0 || (uint32_t)py >= y1) continue;
             size_t pix = (size_t)py * W + px;
             float best = INFINITY; int32_t best_id = -1; Triangle best_tri; std::string best_obj;
             for (const auto& pair : om->objTriangles) {

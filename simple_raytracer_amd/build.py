@@ -33,7 +33,7 @@ def _stale(target, sources):
 
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, "srt_hip.hip")]
-    deps = srcs + [os.path.join(CSRC, "srt_device.h"), os.path.join(CSRC, "srt_kernels.h"), os.path.join(HERE, "..", "include", "srt.h")]
+    deps = srcs + [os.path.join(CSRC, "srt_device.h"), os.path.join(CSRC, "srt_kernels.h"), os.path.join(CSRC, "srt_packet.h"), os.path.join(HERE, "..", "include", "srt.h")]
     if not force and not _stale(LIB_HIP, deps):
         return LIB_HIP
     cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_HIP] + srcs

@@ -67,6 +67,24 @@ int srth_om_add_textured_object(void* om_, const char* name, uint32_t n, const f
         }
     })
 }
+// object with several textures (house.obj): per triangle an index into the newline-separated `names`, -1 = untextured
+int srth_om_add_multi_textured_object(void* om_, const char* name, uint32_t n, const float* points, const float* texcoord,
+                                      const int32_t* tri_tex, const char* names) {
+    int rc = srth_om_add_object(om_, name, n, points);
+    if (rc) return rc;
+    GUARD({
+        std::vector<std::string> list;
+        for (const char* p = names; *p;) { const char* e = std::strchr(p, '\n'); if (!e) e = p + std::strlen(p); list.emplace_back(p, e); p = *e ? e + 1 : e; }
+        std::vector<Triangle>& tris = ((ObjectManager*)om_)->objTriangles[name];
+        for (uint32_t i = 0; i < n; i++) {
+            if (tri_tex[i] < 0) continue;
+            tris[i].colorOneCoordinate = vec2(texcoord[i * 6], texcoord[i * 6 + 1]);
+            tris[i].colorTwoCoordinate = vec2(texcoord[i * 6 + 2], texcoord[i * 6 + 3]);
+            tris[i].colorThreeCoordinate = vec2(texcoord[i * 6 + 4], texcoord[i * 6 + 5]);
+            tris[i].textureName = list.at((size_t)tri_tex[i]);
+        }
+    })
+}
 // objTriangles[dst] = getTriangles(src), as main() clones objects (simple_raytracer.cpp:565,597,644)
 int srth_om_clone(void* om_, const char* src, const char* dst) {
     GUARD({ ObjectManager* om = (ObjectManager*)om_; std::vector<Triangle> t = om->getTriangles(src); om->objTriangles[dst] = t; })

@@ -21,6 +21,7 @@
 using namespace srt;
 
 #include "srt_kernels.h"
+#include "srt_packet.h"
 
 // =================================================================================================
 // Host side of the ABI
@@ -48,6 +49,7 @@ static inline void alloc_gate() {
     if (n > 0) throw std::bad_alloc();
 }
 
+constexpr double PACKET_OVERLAP_THRESHOLD = 150.;     // expected slab tests per ray from which primary rays use the packet walk (measured: DESIGN.md s5)
 constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
 
 struct srt_scene {
@@ -64,6 +66,9 @@ struct srt_scene {
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
+    uint32_t* ws_qlist = nullptr; uint32_t* d_qcount = nullptr; uint32_t qcap = 0;      // quadrants with hits: 64 shard lists of qcap entries, their counters
+    double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
+    bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
     float* ws_acc = nullptr; float* ws_sub = nullptr; int32_t* ws_sub_hit = nullptr; float* ws_sub_t = nullptr; size_t ws_acc_pixels = 0;
     int n_cu = 256;
     hipEvent_t ev[RING][4] = {};     // start, closest-hit done, shadow done, shade done
@@ -185,6 +190,8 @@ int srt_scene_destroy(srt_scene* s) {
     if (s->ws_lin) (void)hipFree(s->ws_lin);
     if (s->ws_rgb8) (void)hipFree(s->ws_rgb8);
     if (s->ws_shadow) (void)hipFree(s->ws_shadow);
+    if (s->ws_qlist) (void)hipFree(s->ws_qlist);
+    if (s->d_qcount) (void)hipFree(s->d_qcount);
     if (s->ws_acc) (void)hipFree(s->ws_acc);
     if (s->ws_sub) (void)hipFree(s->ws_sub);
     if (s->ws_sub_hit) (void)hipFree(s->ws_sub_hit);
@@ -274,6 +281,35 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     std::vector<DevNode> nodes; std::vector<int2> ranges;
     int rc = build_device_records(d, nodes, ranges);
     if (rc != SRT_OK) return rc;
+    // How many slab tests does a ray cost?  Surface-area estimate: a random line that crosses the scene's bounds crosses a
+    // convex box inside them with probability area(box) / area(bounds), and a node is tested when its parent's box is
+    // crossed.  A good hierarchy gives a few dozen (bunny: boxes shrink with depth); a median split by first vertex of a
+    // random soup gives thousands (boxes stay as wide as the scene in two axes).  In the second case neighbouring rays
+    // test nearly the same nodes and the packet walk (srt_packet.h) wins for primary rays as well.
+    double overlap = 0.;
+    {
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        auto area = [](const float* a, const float* b) -> double {
+            const double x = (double)b[0] - a[0], y = (double)b[1] - a[1], z = (double)b[2] - a[2];
+            return (x < 0 || y < 0 || z < 0) ? 0. : x * y + y * z + z * x;
+        };
+        for (const int2& r : ranges) {
+            const DevNode& n = nodes[r.x];
+            const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
+            if (area(mn, mx) <= 0.) continue;
+            for (int a = 0; a < 3; a++) { lo[a] = mn[a] < lo[a] ? mn[a] : lo[a]; hi[a] = mx[a] > hi[a] ? mx[a] : hi[a]; }
+        }
+        const double total = area(lo, hi);
+        if (total > 0.) {
+            double sum = 0.;
+            for (const DevNode& n : nodes) {
+                if (n.leaf >= 0) continue;                       // the children of an inner node are tested when its box is crossed
+                const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
+                sum += 2. * area(mn, mx);
+            }
+            overlap = (double)ranges.size() + sum / total;      // + every root
+        }
+    }
     std::vector<DevTri> tris(d->n_tris);
     std::vector<DevTriO> tris_o(d->n_tris);
     {   // per-triangle records: independent, so big scenes are cut over a few host threads (a scene made per frame by a
@@ -307,6 +343,12 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
     UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
     UP(upload(s, ranges.data(), ranges.size(), &s->dev.obj_range));
+    {   // first triangle of each object (the layout contract makes tri_obj non-decreasing)
+        std::vector<int32_t> first(d->n_objects + 1, (int32_t)d->n_tris);
+        for (uint32_t i = d->n_tris; i-- > 0;) first[d->tri_obj[i]] = (int32_t)i;
+        for (uint32_t k = d->n_objects; k-- > 0;) if (first[k] > first[k + 1]) first[k] = first[k + 1];      // objects without triangles
+        UP(upload(s, first.data(), first.size(), &s->dev.obj_tri_first));
+    }
     UP(upload(s, d->obj_color, (size_t)d->n_objects * 3, &s->dev.obj_color));
     UP(upload(s, d->obj_material, (size_t)d->n_objects * 3, &s->dev.obj_mat));
     if (d->tri_normals && d->n_tris) UP(upload(s, d->tri_normals, (size_t)d->n_tris * 9, &s->dev.tri_normals));
@@ -330,8 +372,12 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     }
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
+    s->overlap = overlap;
+    s->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
     hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_qcount, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -412,13 +458,17 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     unsigned long long* ctr = s->d_counters + (s->render_seq & 1) * NCTR;
     unsigned long long* ctr_next = s->d_counters + ((s->render_seq + 1) & 1) * NCTR;
     // a render that failed half-way may have left either set dirty: clear both before the next one
-    if (s->ctr_dirty) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long), stream));
+    if (s->ctr_dirty) {
+        HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t), stream));
+    }
     s->ctr_dirty = true;
     // a counting run must not inherit whatever replayed graphs left in the set (their frames use fixed sets)
     if (p->flags & SRT_FLAG_COUNT_WORK) HIP_TRY(hipMemsetAsync(ctr, 0, NCTR * sizeof(unsigned long long), stream));
 
     DevParams dp;
     dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
+    dp.shadow_px_major = 0u;
     dp.xcd_rows = (s->bytes > (32ull << 20) || variant_of(p) == 18) ? 1u : 0u;       // records far beyond one XCD's 4 MiB L2 (variant 18: forced, for the tests)
     dp.W = p->width; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
@@ -431,16 +481,30 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
     const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);          // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
-    const uint32_t variant = (p->flags >> 8) & 0xffu;      // experimental kernel selector (0 = shipped pipeline)
+    uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
+    const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
+    if (force_nq || variant == 25 || variant == 26) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records by scalar loads (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
-    const size_t shadow_words = (size_t)grid8.x * grid8.y * (p->n_lights ? p->n_lights : 1);
+    // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
+    // samples, packet shadow kernel): room for either
+    const size_t words_tile = (size_t)grid8.x * grid8.y * (p->n_lights ? p->n_lights : 1), words_px = pixels * ((p->n_lights + 63) / 64);
+    const size_t shadow_words = words_tile > words_px ? words_tile : words_px;
     if (variant != 1 && s->ws_shadow_words < shadow_words) {
         HIP_TRY(wait_idle(s));
         if (s->ws_shadow) (void)hipFree(s->ws_shadow);
         s->ws_shadow = nullptr; s->ws_shadow_words = 0;
         HIP_TRY(hipMalloc((void**)&s->ws_shadow, shadow_words * sizeof(unsigned long long)));
         s->ws_shadow_words = shadow_words;
+    }
+    const size_t n_tiles = (size_t)grid8.x * grid8.y;
+    const uint32_t qcap_need = (uint32_t)((n_tiles + QL_SHARDS - 1) / QL_SHARDS) * 4u;      // a shard gets every 64th tile, four quadrants each
+    if (variant != 1 && s->qcap < qcap_need) {
+        HIP_TRY(wait_idle(s));
+        if (s->ws_qlist) (void)hipFree(s->ws_qlist);
+        s->ws_qlist = nullptr; s->qcap = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws_qlist, (size_t)QL_SHARDS * qcap_need * 2 * sizeof(uint32_t)));      // two words per entry
+        s->qcap = qcap_need;
     }
     if (spp > 1 && s->ws_acc_pixels < pixels) {                    // supersampling extension: accumulation buffers
         HIP_TRY(wait_idle(s));
@@ -472,14 +536,24 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         // closest-hit kernel: CAP = node queue entries, TWL/THL = log2 tile size per wave, FILTER = filtered slab test
         #define LAUNCH_NQ(CAP, TWL, THL, FILTER) do { \
             const dim3 g_((p->width + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
-            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); \
-            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr); } while (0)
-        // From 8 light samples on: closest hit and shadow rays as two launches, the samples cut into (up to) four chunks over
-        // blockIdx.z.  A wave that walks its 16 pixels x all samples through dense geometry alone outlasts the rest of the
-        // launch (K4 shape: 3.9 -> 2.5 ms per frame; K3 with 16 samples: 0.89 -> 0.64 ms); below 8 the fused kernel wins.
+            if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap); \
+            else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap); } while (0)
+        // Pipelines (variant 0 picks per scene and light count; the numbered variants force one):
+        //   fused        k_trace_nq (node-queue closest hit + shadow rays in one launch): 1..7 light samples
+        //   nq + pk      node-queue closest hit, then the packet shadow kernel over the list of quadrants with hits: 8+ light samples
+        //                (the samples of a pixel walk the other objects' trees in lock step), or variant 21 at any count
+        //   pk + nq      packet closest hit, then the node-queue shadow kernel: hierarchies of heavily overlapping boxes (the 1 M soup:
+        //                neighbouring primary rays test the same ~2,500 nodes, while the shadow rays of a tile start all over the
+        //                scene), 1..7 light samples, or variant 23
+        //   pk + pk      both packet kernels: such scenes with 8+ light samples, or variant 22
+        //   nq chunked   the round-1 form for 8+ samples (k_shadow_nq, 64 rays in flight, samples cut over blockIdx.z): variant 20
+        const bool pk_closest = variant == 22 || variant == 23 || (variant == 0 && s->prefer_packet && !force_nq);
+        const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
+        uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
+        uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
-        const bool chunked = p->n_lights >= 8 && !count && (variant == 0 || variant == 20);
-        const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked;     // (variants 11, 17, 18 are configurations of the fused kernel)
+        const bool chunked = p->n_lights >= 8 && !count && variant == 20;
+        const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked && !pk_shadow && !pk_closest && variant != 20;     // (variants 11, 17, 18 are configurations of the fused kernel)
         const dim3 grid8x(grid8.x, fp.xcd_rows ? (grid8.y + 7) / 8 * 8 : grid8.y);      // whole tile rows per XCD: y padded to 8 rows
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
@@ -491,12 +565,16 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         case 6: LAUNCH_NQ(160, 2, 2, true); break;       // tiny node queue + filtered slab test: the overflow walk as shipped
         case 5: LAUNCH_NQ(1024, 3, 2, false); break;     // 8x4 pixels per wave, 1024-entry queue (tile-size experiment)
         case 10: LAUNCH_NQ(512, 2, 2, true); break;      // shipped kernels, unfused (closest hit, then shadow)
-        default:                                           // shipped: closest hit + shadow rays fused in one launch
-            if (fused) {
+        default:
+            if (pk_closest) {          // one wavefront per 8x8 tile walks the trees in lock step; a workgroup = 2 x 2 tiles
+                const dim3 gp((grid8.x + 1) / 2, fp.xcd_rows ? ((grid8.y + 1) / 2 + 7) / 8 * 8 : (grid8.y + 1) / 2);
+                if (count)            hipLaunchKernelGGL((k_closest_hit_pk<true, true, false>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+                else if (fp.xcd_rows) hipLaunchKernelGGL((k_closest_hit_pk<false, true, true>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+                else                  hipLaunchKernelGGL((k_closest_hit_pk<false, true, false>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+            } else if (fused) {        // closest hit + shadow rays in one launch
                 if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
-                else if (variant == 17 || (variant == 0 && p->n_lights >= 8))      // many light samples: 64 shadow rays in flight per wave
-                                        hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else {
@@ -507,7 +585,16 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         #undef LAUNCH_NQ
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
-        if (p->n_lights && !fused) {
+        if (pk_shadow) {
+            // a fixed number of waves pull units (the shadow rays of 64 / n_lights pixels) from the quadrant list: no grid over the image
+            const uint64_t max_entries = (uint64_t)n_tiles * 4u;
+            const uint32_t wgs = (uint32_t)(max_entries < (uint64_t)s->n_cu * 8 ? max_entries : (uint64_t)s->n_cu * 8);
+            const uint32_t lc_shape = (p->flags >> 8 & 0xffu) == 26 ? 4u : 8u;       // walk shape: 8 pixels x 8 samples; 26: 16 pixels x 4 samples (A/B)
+            if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);
+            else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);   // records by scalar loads (A/B)
+            else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);
+            HIP_TRY(hipGetLastError());
+        } else if (p->n_lights && !fused) {
             if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64, 6>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
                                                       s->dev, fp, o_hit, o_t, s->ws_shadow, ctr, L_CHUNK);
             else if (count)        hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
@@ -518,7 +605,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             HIP_TRY(hipGetLastError());
         }
         if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next);
+        DevParams sp = fp;
+        sp.shadow_px_major = pk_shadow ? 1u : 0u;
+        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
         HIP_TRY(hipGetLastError());
         return SRT_OK;
     };
@@ -603,6 +692,9 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
         s->last.tri_tests_primary = s->h_counters[2];
         s->last.node_tests_shadow = s->h_counters[3];
         s->last.tri_tests_shadow = s->h_counters[4];
+        if (std::getenv("SRT_DIAG_COUNTERS"))      // counting build of the packet shadow kernel: shape of its walks
+            std::fprintf(stderr, "srt diag: walks %llu steps %llu node-window loads %llu triangle iterations %llu | lane tests: nodes %llu tris %llu\n",
+                         s->h_counters[0], s->h_counters[5], s->h_counters[6], s->h_counters[7], s->h_counters[3], s->h_counters[4]);
         s->pending = false;
     }
     if (stats) *stats = s->last;

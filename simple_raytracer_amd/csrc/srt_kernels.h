@@ -21,6 +21,7 @@ struct DevScene {
     const float* obj_color;       // n_objects x 3
     const float* obj_mat;         // n_objects x 3
     const int2* obj_range;        // n_objects: [first node, end node) in pre-order
+    const int32_t* obj_tri_first; // n_objects + 1: first triangle id of each object (triangles are numbered object by object)
     const uint8_t* tex;
     const unsigned long long* tex_off;
     const uint32_t* tex_w;
@@ -41,6 +42,7 @@ struct DevParams {
     uint32_t bg;                  // r | g << 8 | b << 16
     uint32_t smooth;              // interpolateNormal mode (simple_raytracer.cpp:132-140,162)
     uint32_t xcd_rows;            // host-side choice of the k_trace_nq build that deals whole tile rows to XCDs
+    uint32_t shadow_px_major;     // shadow bits as the packet shadow kernel writes them: per pixel one u64 per 64 light samples
 };
 
 // counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
@@ -277,6 +279,18 @@ __global__ __launch_bounds__(256) void k_closest_hit_q(DevScene s, DevParams p, 
 // If the node queue cannot take a step's children the wave finishes those subtrees with the stackless
 // pre-order walk (skip links) instead -- any tree shape is handled with bounded LDS.
 // =================================================================================================
+// ---- list of quadrants (4x4 pixels) with hits: what the packet shadow kernel (srt_packet.h) works through ----------------
+constexpr int QL_SHARDS = 64;            // shard lists; a quadrant goes to shard (tile index & 63)
+constexpr int QL_STRIDE = 16;            // counters 64 B apart
+// entry = two words: tile index << 2 | quadrant, and the quadrant's 16-bit hit mask (bit = y * 4 + x).  Called by one lane of a
+// wave whose quadrant has a hit.
+__device__ __forceinline__ void quadrant_list_append(uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap,
+                                                     uint32_t tile_index, uint32_t quadrant, uint32_t hit_mask) {
+    const uint32_t shard = tile_index & (QL_SHARDS - 1);
+    const uint32_t slot = atomicAdd(qcount + shard * QL_STRIDE, 1u);
+    if (slot < qcap) reinterpret_cast<uint2*>(qlist)[(size_t)shard * qcap + slot] = make_uint2((tile_index << 2) | quadrant, hit_mask);
+}
+
 constexpr int NQ_P = 16;                    // rays per wavefront of the shadow kernel (4x4 pixel quadrant)
 constexpr int LQ_WORDS = 2 * (64 + 64);     // (leaf, ray) pair queue of the node-queue kernels: < 64 left over + <= 64 per push, 2 words each
 
@@ -306,7 +320,8 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d,
                                                   const uint32_t bx, const uint32_t by, const uint32_t gx,      // workgroup tile coordinates, tiles per row
-                                                  const uint32_t wave) {                                        // quadrant of the tile this wave owns
+                                                  const uint32_t wave,                                          // quadrant of the tile this wave owns
+                                                  uint32_t* __restrict__ qcount = nullptr, uint32_t* __restrict__ qlist = nullptr, uint32_t qcap = 0) {   // list of quadrants with hits (4x4 waves only)
     constexpr int P = 1 << (TWL + THL);           // rays per wavefront
     const uint32_t lane = threadIdx.x & 63;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
@@ -532,6 +547,10 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         out_id = id; out_t = t;
     }
     count_hits(counters, is_hit, by * gx + bx);
+    if (TWL == 2 && THL == 2 && qlist) {
+        const unsigned long long hm = __ballot(is_hit);          // all lanes vote: not inside the lane-0 branch
+        if (lane == 0 && hm) quadrant_list_append(qcount, qlist, qcap, by * gx + bx, wave, (uint32_t)hm);
+    }
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
 
@@ -590,7 +609,8 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
 template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
 __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
-                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters) {
+                                                        uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
+                                                        uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap) {
     constexpr int P = 1 << (TWL + THL);
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
@@ -600,7 +620,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     int32_t id; float t; V3 d;
     if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x)) return;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave);
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave, qcount, qlist, qcap);
 }
 
 // =================================================================================================
@@ -1006,8 +1026,10 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
                                                     const float* __restrict__ t_in,
                                                     const unsigned long long* __restrict__ shadow_bits,
                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                    unsigned long long* __restrict__ counters_next) {
+                                                    unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
     if (counters_next) zero_next_counters(counters_next);
+    // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
+    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
 #ifdef SRT_DIAG
     rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
 #endif
@@ -1051,12 +1073,14 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
                                 (bc.x * n9[2] + bc.y * n9[5]) + bc.z * n9[8]));
     }
     V3 sum = mk(0.0f, 0.0f, 0.0f);
-    const unsigned long long* sb = shadow_bits + tile_index * p.n_lights;
-    // the tile's word: one 16-bit field per 4x4 quadrant (the wave that traced it), bit = y * 4 + x inside the quadrant
+    // shadow bits, tile-major (node-queue kernels): per tile and light sample one word, one 16-bit field per 4x4 quadrant (the wave
+    // that traced it), bit = y * 4 + x inside the quadrant; pixel-major (packet shadow kernel): per pixel one word per 64 samples
+    const uint32_t n_lch = (p.n_lights + 63u) >> 6;
+    const unsigned long long* sb = p.shadow_px_major ? shadow_bits + pix * n_lch : shadow_bits + tile_index * p.n_lights;
     const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-        const bool shadowed = (sb[l] >> sbit) & 1ull;
+        const bool shadowed = p.shadow_px_major ? ((sb[l >> 6] >> (l & 63u)) & 1ull) : ((sb[l] >> sbit) & 1ull);
         V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
         if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
         sum = sum + c;                                                                          // :370

@@ -1,0 +1,410 @@
+// srt_packet.h -- wave-coherent "packet" traversal kernels (gfx950).  Included by srt_hip.hip after srt_kernels.h.
+//
+// The reference's traversal (boundingBoxIntersection, simple_raytracer.cpp:296-317) tests, for one ray, every node whose
+// ancestors all pass the slab test.  On the pre-order node array that is the stackless walk  i = pass ? i + 1 : skip[i].
+// Here the 64 rays of a wavefront run that walk IN LOCK STEP: every lane keeps the index `n` of the next node its own walk
+// would visit, the wave visits i = min n, and the lanes with n == i test node i.  A lane's n only ever grows, so every
+// (node, ray) pair of the reference's candidate set is tested exactly once and in the reference's own visit order per ray
+// -- closest hit needs no merge (a lane meets its triangles in increasing id order: strict '<' keeps the first, :429) and
+// the any-hit walk of a shadow ray stops exactly where the sequential walk stops, so the work counts ARE the algorithmic
+// counts the CPU oracle mirrors.
+//
+// What the lock step buys: the node index is wave-uniform, so node and triangle records come through the SCALAR cache
+// (s_load_dwordx8 / x4: once per wave instead of once per lane, no VGPRs, no LDS queues, no ballot-prefix pushes) and
+// the slab / Moller-Trumbore tests take their box / triangle operands from SGPRs.  It pays when the rays of a wave
+// visit mostly the same nodes: the light samples of one pixel (same origin, directions a 3-unit staircase apart on a
+// ~600-unit lever, softShadow:363-383), and primary rays through a hierarchy of heavily overlapping boxes (the 1 M
+// triangle soup: ~2,500 slab tests per ray, nearly all shared by the 8x8 pixels of a tile).  Where rays of a tile part
+// ways deep in a good hierarchy (bunny at 1080p) the node-queue kernels of srt_kernels.h keep lanes fuller.
+#pragma once
+#include "srt_kernels.h"
+
+// wave-uniform minimum of a per-lane index (rare path of the walk: every lane that could have continued at the expected
+// successor dropped out -- shadowed, or jumping over its own object)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Slab test of one node for the active lanes: filtered form first, the reference's comparisons with exact divides where the
+// filter cannot decide (srt_device.h).  Box operands are wave-uniform.
+template <bool FILTER>
+__device__ __forceinline__ bool packet_slab(V3 o, V3 d, RayRcp rc, const DevNode& nd) {
+    if (FILTER) {
+        bool amb;
+        bool pass = ray_aabb_filtered(o, rc, nd.minx, nd.miny, nd.minz, nd.maxx, nd.maxy, nd.maxz, amb);
+        if (amb) pass = ray_aabb_nb(o, d, nd.minx, nd.miny, nd.minz, nd.maxx, nd.maxy, nd.maxz);
+        return pass;
+    }
+    return ray_aabb_nb(o, d, nd.minx, nd.miny, nd.minz, nd.maxx, nd.maxy, nd.maxz);
+}
+
+// ---- any-hit packet walk (shadowIntersection:321-342) -----------------------------------------------------------------
+// valid lanes carry a shadow ray (origin ro = d*t, direction rd = L - d*t, :325-326) and the node range `self` of the hit
+// object, which the walk jumps over (the reference walks it and discards the result, :328/:331).  Returns "shadowed".
+template <bool COUNT, bool FILTER>
+__device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self,
+                                               unsigned long long& n_node, unsigned long long& n_tri) {
+    const uint32_t N = s.n_nodes;
+    const RayRcp rc = ray_rcp(rd);
+    uint32_t n = valid ? 0u : N;
+    if (n == (uint32_t)self.x) n = (uint32_t)self.y;
+    bool flag = false;
+    uint32_t i = wave_min_u32(n);
+    while (i < N) {
+        const DevNode nd = s.nodes[i];                          // wave-uniform index: scalar loads
+        const bool act = n == i;
+        bool pass = false;
+        if (act) {
+            if (COUNT) n_node++;
+            pass = packet_slab<FILTER>(ro, rd, rc, nd);
+        }
+        uint32_t cand;
+        if (nd.leaf >= 0) {
+            const uint32_t first = (uint32_t)nd.leaf >> LEAF_SHIFT, cnt = (uint32_t)nd.leaf & LEAF_MAX;
+            bool todo = pass;
+            for (uint32_t k = 0; k < cnt && __ballot(todo); k++) {
+                const DevTri tr = s.tris[first + k];            // wave-uniform
+                if (todo) {
+                    if (COUNT) n_tri++;
+                    const float t = ray_triangle(ro, rd, mk(tr.p1x, tr.p1y, tr.p1z), mk(tr.e1x, tr.e1y, tr.e1z), mk(tr.e2x, tr.e2y, tr.e2z));
+                    if (t != SRT_NEG_INF) { flag = true; todo = false; }      // any t >= 0, NaN included (:335)
+                }
+            }
+            if (act) n = flag ? N : i + 1u;
+            cand = i + 1u;
+        } else {
+            if (act) n = pass ? i + 1u : (uint32_t)nd.skip;
+            cand = __ballot(pass) ? i + 1u : (uint32_t)nd.skip;
+        }
+        if (n == (uint32_t)self.x) n = (uint32_t)self.y;        // never the hit object's own tree
+        i = __ballot(n == cand) ? cand : wave_min_u32(n);       // no lane is behind cand (see header): usually one is AT it
+    }
+    return flag;
+}
+
+// ---- any-hit packet walk through LDS windows ------------------------------------------------------------------------------------
+// Same walk, same results and counts as packet_any_hit, but the records come from two per-wave LDS windows instead of one scalar
+// load per step: a step of the scalar form costs a dependent scalar-cache / L2 round trip (measured on the K3 scene with 16 light
+// samples: ~860 cycles per step, 69 % of the wave-cycles waiting), and the walk only ever moves FORWARD through the pre-order node
+// array (i + 1 or skip[i] > i) and, with it, through the triangle array (leaves lie in visit order).  So the wave loads the next
+// 64 nodes (2 KB, one coalesced 2 x dwordx4 per lane) when the walk leaves its window and reads node i from LDS with a
+// wave-uniform address (a broadcast); likewise the next 64 triangles (3 KB) when a leaf reaches past the window.  Deep in a tree
+// most steps stay inside the window (a subtree of depth 6 is 63 consecutive records).
+struct PkWindows {
+    float4 na[64], nb[64];               // nodes base .. base + 63: min.xyz max.x | max.yz skip leaf
+    float4 t0[64], t1[64], t2[64];       // triangles base .. base + 63 (DevTri)
+};
+template <bool COUNT, bool FILTER>
+__device__ __forceinline__ bool packet_any_hit_win(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self, PkWindows& w,
+                                                   uint32_t& nbase, uint32_t& tbase, unsigned long long& n_node, unsigned long long& n_tri,
+                                                   unsigned long long* diag = nullptr) {      // counting build: [0] steps [1] node-window loads [2] triangle iterations [3] triangle-window loads
+    const uint32_t N = s.n_nodes, NT = s.n_tris;
+    const uint32_t lane = threadIdx.x & 63;
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
+    const RayRcp rc = ray_rcp(rd);
+    uint32_t n = valid ? 0u : N;
+    if (n == (uint32_t)self.x) n = (uint32_t)self.y;
+    bool flag = false;
+    uint32_t i = wave_min_u32(n);
+    while (i < N) {
+        if (i - nbase >= 64u) {                                  // the walk left the node window (which outlives the walk): load nodes i .. i + 63
+            nbase = i;
+            const uint32_t j = nbase + lane;
+            if (j < N) { w.na[lane] = nodes4[2 * (size_t)j]; w.nb[lane] = nodes4[2 * (size_t)j + 1]; }
+            __builtin_amdgcn_wave_barrier();
+            if (COUNT && diag) diag[1]++;
+        }
+        const float4 a = w.na[i - nbase], b = w.nb[i - nbase];   // wave-uniform address: broadcast
+        if (COUNT && diag) diag[0]++;
+        const int32_t skip = __builtin_amdgcn_readfirstlane(__float_as_int(b.z)), leaf = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
+        const bool act = n == i;
+        bool pass = false;
+        if (act) {
+            if (COUNT) n_node++;
+            if (FILTER) {
+                bool amb;
+                pass = ray_aabb_filtered(ro, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
+                if (amb) pass = ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y);
+            } else pass = ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y);
+        }
+        uint32_t cand;
+        if (leaf >= 0) {
+            const uint32_t first = (uint32_t)leaf >> LEAF_SHIFT, cnt = (uint32_t)leaf & LEAF_MAX;
+            bool todo = pass;
+            if (cnt && __ballot(todo)) {
+                if (first - tbase > 64u - cnt) {                 // the leaf reaches past the triangle window (cnt <= 31): load first .. first + 63
+                    tbase = first;
+                    const uint32_t j = tbase + lane;
+                    if (j < NT) { w.t0[lane] = tris4[3 * (size_t)j]; w.t1[lane] = tris4[3 * (size_t)j + 1]; w.t2[lane] = tris4[3 * (size_t)j + 2]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (COUNT && diag) diag[3]++;
+                }
+                const uint32_t tw = first - tbase;
+                for (uint32_t k = 0; k < cnt && __ballot(todo); k++) {
+                    if (COUNT && diag) diag[2]++;
+                    const float4 q0 = w.t0[tw + k], q1 = w.t1[tw + k];
+                    const float e2z = w.t2[tw + k].x;
+                    if (todo) {
+                        if (COUNT) n_tri++;
+                        const float t = ray_triangle(ro, rd, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, e2z));
+                        if (t != SRT_NEG_INF) { flag = true; todo = false; }      // any t >= 0, NaN included (:335)
+                    }
+                }
+            }
+            if (act) n = flag ? N : i + 1u;
+            cand = i + 1u;
+        } else {
+            if (act) n = pass ? i + 1u : (uint32_t)skip;
+            cand = __ballot(pass) ? i + 1u : (uint32_t)skip;
+        }
+        if (n == (uint32_t)self.x) n = (uint32_t)self.y;        // never the hit object's own tree
+        i = __ballot(n == cand) ? cand : wave_min_u32(n);
+    }
+    return flag;
+}
+
+// ---- closest-hit packet walk for rays from the origin (rayIntersection:405-431) ------------------------------------------
+template <bool COUNT, bool FILTER>
+__device__ __forceinline__ void packet_closest_hit(const DevScene& s, bool valid, V3 d, float& best, int32_t& best_id,
+                                                   unsigned long long& n_node, unsigned long long& n_tri) {
+    const uint32_t N = s.n_nodes;
+    const V3 o = mk(0.f, 0.f, 0.f);
+    const RayRcp rc = ray_rcp(d);
+    uint32_t n = valid ? 0u : N;
+    best = __builtin_inff(); best_id = -1;
+    uint32_t i = valid ? 0u : N;
+    i = wave_min_u32(i);
+    while (i < N) {
+        const DevNode nd = s.nodes[i];
+        const bool act = n == i;
+        bool pass = false;
+        if (act) {
+            if (COUNT) n_node++;
+            pass = packet_slab<FILTER>(o, d, rc, nd);
+        }
+        uint32_t cand;
+        if (nd.leaf >= 0) {
+            const uint32_t first = (uint32_t)nd.leaf >> LEAF_SHIFT, cnt = (uint32_t)nd.leaf & LEAF_MAX;
+            if (__ballot(pass)) {
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const DevTriO tr = s.tris_o[first + k];     // wave-uniform
+                    if (pass) {
+                        if (COUNT) n_tri++;
+                        const float t = ray_triangle_origin(d, mk(tr.tx, tr.ty, tr.tz), mk(tr.e1x, tr.e1y, tr.e1z), mk(tr.e2x, tr.e2y, tr.e2z),
+                                                            mk(tr.qx, tr.qy, tr.qz));
+                        if (t != SRT_NEG_INF && t < best) { best = t; best_id = (int32_t)(first + k); }      // strict '<', ids rise (:429)
+                    }
+                }
+            }
+            if (act) n = i + 1u;
+            cand = i + 1u;
+        } else {
+            if (act) n = pass ? i + 1u : (uint32_t)nd.skip;
+            cand = __ballot(pass) ? i + 1u : (uint32_t)nd.skip;
+        }
+        i = __ballot(n == cand) ? cand : wave_min_u32(n);
+    }
+}
+
+// Pixel of lane l in an 8x8 tile, "quadrant layout": bits 5:4 = 4x4 quadrant, 3:2 = row, 1:0 = column inside it.  A ballot
+// over the lanes of a tile IS a word of the tile's shadow-bit / hit-mask format (srt_kernels.h).
+__device__ __forceinline__ void tile_lane_pixel(uint32_t bx, uint32_t by, uint32_t lane, uint32_t& px, uint32_t& r) {
+    const uint32_t q = lane >> 4, ql = lane & 15u;
+    px = bx * 8u + (q & 1u) * 4u + (ql & 3u);
+    r = by * 8u + (q >> 1) * 4u + (ql >> 2);
+}
+
+// workgroup (4 waves) -> 8x8 tiles.  XCD_ROWS: whole tile rows per XCD (workgroups are dealt round-robin over the 8 XCDs),
+// for scenes far bigger than one XCD's L2; the host pads gridDim.y to a multiple of 8.
+template <bool XCD_ROWS>
+__device__ __forceinline__ bool packet_tile_of_wave(const DevParams& p, uint32_t& bx, uint32_t& by) {
+    const uint32_t gx = gridDim.x;                              // workgroups per row: each covers 2 x 2 tiles
+    uint32_t wx = blockIdx.x, wy = blockIdx.y;
+    if (XCD_ROWS) {
+        const uint32_t w = blockIdx.y * gx + blockIdx.x, idx = w >> 3;
+        wy = (idx / gx) * 8u + (w & 7u); wx = idx % gx;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    bx = wx * 2u + (wave & 1u); by = wy * 2u + (wave >> 1);
+    return bx * 8u < p.W && by * 8u < p.rows;
+}
+
+// =================================================================================================
+// Closest hit, packet form: one wavefront per 8x8 pixel tile.  Writes hit ids, t, the final pixel of a miss, the hit-pixel
+// statistic and (qlist != null) the tile's quadrants with hits into the quadrant list.
+// =================================================================================================
+template <bool COUNT, bool FILTER, bool XCD_ROWS>
+__global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                        float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                        uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap,
+                                                        unsigned long long* __restrict__ counters) {
+    uint32_t bx, by;
+    if (!packet_tile_of_wave<XCD_ROWS>(p, bx, by)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t px, r;
+    tile_lane_pixel(bx, by, lane, px, r);
+    const bool live = px < p.W && r < p.rows;
+    const V3 d = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
+    unsigned long long n_node = 0, n_tri = 0;
+    float best; int32_t id;
+    packet_closest_hit<COUNT, FILTER>(s, live, d, best, id, n_node, n_tri);
+    const uint32_t tiles_x = (p.W + 7u) / 8u;
+    if (live) {
+        const size_t pix = (size_t)r * p.W + px;
+        hit_id[pix] = id;
+        t_out[pix] = best;
+        if (id < 0) {      // a miss is final here: zero light sum, background pixel (:518, drawImage:476-487)
+            if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+            if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+        }
+    }
+    const unsigned long long hm = __ballot(live && id >= 0);
+    if (lane == 0 && hm) {
+        const uint32_t tile_index = by * tiles_x + bx;
+        atomicAdd(counters + CTR_HIT_BASE + 8 * (tile_index & (HIT_SHARDS - 1)), (unsigned long long)__popcll(hm));
+        if (qlist)
+            for (uint32_t q = 0; q < 4; q++) if ((hm >> (16 * q)) & 0xffffull) quadrant_list_append(qcount, qlist, qcap, tile_index, q, (uint32_t)(hm >> (16 * q)) & 0xffffu);
+    }
+    if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
+}
+
+// =================================================================================================
+// Shadow rays, packet form, fed from the list of 4x4-pixel quadrants that contain hits.
+//
+// A 3840x2160 frame of the reference's scenes is mostly sky: 129,600 tiles of which a tenth contain a hit.  A grid over all
+// tiles (x light-sample chunks) is bound by workgroup dispatch, not by work (measured: 2.07 M waves launched, 23 % of the wave
+// slots occupied), and a tile in a tree crown is a long workgroup.  So the closest-hit kernels append every quadrant with a
+// hit to a list -- 64 shard lists with their own counters, one atomic per wave with hits -- and this kernel is a fixed-size
+// grid of workgroups that pull quadrants from it: entry e belongs to fetch shard e % 64, a workgroup takes the next entry of
+// its home shard with one atomic (issued one entry ahead) and moves on to shards that still have entries when its own is empty.
+//
+// Wave 0 unpacks the quadrant once (hit pixels -> shadow-ray origin d*t and own-object range, in LDS); then the four waves take
+// packet walks from it through an LDS counter.  A walk = 8 hit pixels x 8 consecutive light samples = at most 64 shadow rays that
+// stay close together all the way: 8 samples move the light by at most 9 units per axis on a ~600-unit lever, 8 neighbouring
+// pixels start within a unit of each other (measured against the alternatives: 64 samples of ONE pixel fan out over ~5 units
+// at the far side of the scene and part ways in the tree crowns -- 1.9 ms on the K4 shape against 0.9 for 16 pixels x 4
+// samples).  A quadrant in a tree crown with 64 samples is 16 long walks: shared by four waves it is four walks
+// long, not sixteen.
+// Result, pixel-major: per hit pixel one u64 per 64 light samples, bit = sample; a walk owns one BYTE of a pixel's word (the rays
+// of a pixel are 8 consecutive lanes: a byte of the ballot), so there are no atomics.
+// =================================================================================================
+struct PkEntryLds {
+    float4 pix_o[16];                    // per hit rank: shadow-ray origin d*t (:326), pixel index (w) as bits
+    int2 pix_self[16];                   // per hit rank: node range of the hit object
+    uint32_t n_walks, next_walk, n_hit, live;
+};
+
+// qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) entries handed out per fetch shard; counters
+// QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
+template <bool COUNT, bool FILTER, bool WINDOWS>
+__global__ __launch_bounds__(256) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
+                                                   uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
+                                                   unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters, uint32_t lc_shape) {
+    __shared__ PkEntryLds E;
+    __shared__ PkWindows win_all[4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t nbase = 0x80000000u, tbase = 0x80000000u;                   // window bases (sentinel: nothing loaded); the windows outlive a walk
+    const uint32_t tiles_x = (p.W + 7u) / 8u;
+    const uint32_t n_lch = (p.n_lights + 63u) >> 6;                       // u64 words per pixel
+    const uint32_t n_lc8 = (p.n_lights + 7u) >> 3;                        // chunks of 8 light samples
+    // walk shape: PG pixels x LC consecutive light samples, PG * LC = 64; a grab = one byte of the pixels' words = 8 samples = 8 / LC walks
+    const uint32_t LC = lc_shape, PG = 64u / LC;
+    const uint32_t pr = lane / LC, lg = lane - pr * LC;                   // this lane's pixel slot and light sample within a walk
+    // wave 0 deals the entries: prefix sum over the shard list lengths (lane k holds shard k), fetch counters, prefetched number
+    uint32_t cnt = 0, incl = 0, n_entries = 0, home = blockIdx.x & (QL_SHARDS - 1), k_next = 0;
+    uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
+    if (wave == 0) {
+        cnt = qcount[lane * QL_STRIDE];
+        cnt = cnt < qcap ? cnt : qcap;
+        incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
+        n_entries = (uint32_t)__shfl((int)incl, 63, 64);
+        if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
+    }
+    unsigned long long n_node = 0, n_tri = 0;
+    unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
+    for (;;) {
+        if (wave == 0) {
+            bool live = true;
+            uint32_t e = 0;
+            for (;;) {
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
+                e = k * QL_SHARDS + home;
+                if (e < n_entries) break;
+                // home shard empty: look (agent-scope loads, the counters only grow) for a shard that still has entries, next after home
+                const uint32_t seen = __hip_atomic_load(fetch + lane * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long open = __ballot((unsigned long long)seen * QL_SHARDS + lane < (unsigned long long)n_entries);
+                if (!open) { live = false; break; }
+                const unsigned long long rot = home == 63u ? open : ((open >> (home + 1u)) | (open << (63u - home)));      // bit j = shard home + 1 + j
+                home = (home + 1u + (uint32_t)__builtin_ctzll(rot)) & (QL_SHARDS - 1);
+                if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
+            }
+            if (live) {
+                if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);    // the next entry's number: in flight during this one
+                const unsigned long long above = __ballot(incl > e);             // first shard list whose inclusive prefix exceeds e
+                const uint32_t shard = (uint32_t)__builtin_ctzll(above);
+                const uint32_t excl = (uint32_t)__shfl((int)(incl - cnt), (int)shard, 64);
+                const uint2 ent = reinterpret_cast<const uint2*>(qlist)[(size_t)shard * qcap + (e - excl)];      // wave-uniform
+                const uint32_t hm = ent.y & 0xffffu, nh = (uint32_t)__popc(hm);
+                const uint32_t tile_index = ent.x >> 2, q = ent.x & 3u;
+                const uint32_t by = tile_index / tiles_x, bx = tile_index - by * tiles_x;
+                if (lane < 16 && ((hm >> lane) & 1u)) {                           // lanes < 16: bit = y * 4 + x inside the quadrant
+                    const uint32_t px = bx * 8u + (q & 1u) * 4u + (lane & 3u), r = by * 8u + (q >> 1) * 4u + (lane >> 2);
+                    const uint32_t pix = r * p.W + px;
+                    const int32_t id = hit_id[pix];
+                    const float t = t_in[pix];
+                    const V3 d = primary_dir(p, px, image_row(p, r));
+                    const V3 so = d * t;                                          // :326
+                    const uint32_t rank = (uint32_t)__popc(hm & ((1u << lane) - 1u));
+                    E.pix_o[rank] = make_float4(so.x, so.y, so.z, __uint_as_float(pix));
+                    E.pix_self[rank] = s.obj_range[s.tri_obj[id]];
+                }
+                if (lane == 0) { E.n_hit = nh; E.n_walks = ((nh + PG - 1u) / PG) * n_lc8; E.next_walk = 0u; }
+            }
+            if (lane == 0) E.live = live ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!E.live) break;
+        const uint32_t n_walks = E.n_walks, nh = E.n_hit;
+        for (;;) {
+            uint32_t wk = 0;
+            if (lane == 0) wk = atomicAdd(&E.next_walk, 1u);
+            wk = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk);
+            if (wk >= n_walks) break;
+            const uint32_t g = wk / n_lc8, lc = wk - g * n_lc8;                  // pixel group (PG hit ranks), byte = chunk of 8 light samples
+            const uint32_t rank = g * PG + pr;
+            V3 so = mk(0.f, 0.f, 0.f);
+            int2 self = make_int2(-1, -1);
+            uint32_t pix = 0;
+            if (rank < nh) {
+                const float4 po = E.pix_o[rank];
+                self = E.pix_self[rank];
+                pix = __float_as_uint(po.w);
+                so = mk(po.x, po.y, po.z);
+            }
+            uint32_t byte = 0;
+            for (uint32_t half = 0; half < 8u; half += LC) {                      // LC = 8: one walk; LC = 4: one per nibble
+                const uint32_t l = lc * 8u + half + lg;
+                const bool valid = rank < nh && l < p.n_lights;
+                V3 sd = mk(0.f, 0.f, 1.f);
+                if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
+                if (COUNT) diag[4]++;
+                const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, win_all[wave], nbase, tbase, n_node, n_tri, diag)
+                                              : packet_any_hit<COUNT, FILTER>(s, valid, so, sd, self, n_node, n_tri);
+                const unsigned long long sm = __ballot(shadowed);
+                byte |= ((uint32_t)(sm >> (pr * LC)) & ((1u << LC) - 1u)) << half;
+            }
+            if (rank < nh && lg == 0 && lc * 8u < p.n_lights) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)byte;
+        }
+        __syncthreads();                                                          // wave 0 rewrites E
+    }
+    if (COUNT) {
+        wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri);
+        // shape of the packet walks (read by srt_sync into the SRT_DIAG_COUNTERS dump): uniform values, lane 0 adds
+        if (lane == 0) { atomicAdd(counters + 5, diag[0]); atomicAdd(counters + 6, diag[1]); atomicAdd(counters + 7, diag[2]); atomicAdd(counters + 0, diag[4]); }
+    }
+}

@@ -37,6 +37,7 @@ def load():
         L.srth_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p]
         L.srth_om_add_texture.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _u8p]
         L.srth_om_add_textured_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p, _f32p, C.c_char_p]
+        L.srth_om_add_multi_textured_object.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, _f32p, _f32p, _i32p, C.c_char_p]
         L.srth_om_set_color.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
         L.srth_om_set_props.argtypes = [C.c_void_p, C.c_char_p] + [C.c_float] * 3
         L.srth_om_transform.argtypes = [C.c_void_p, C.c_char_p, _f32p]
@@ -159,6 +160,15 @@ class ObjectManager:
         tex = np.ascontiguousarray(texture, np.uint8)
         _ok(self.L.srth_om_add_texture(self.om, texname.encode(), tex.shape[1], tex.shape[0], _p(tex, _u8p)))
         _ok(self.L.srth_om_add_textured_object(self.om, name.encode(), pts.shape[0], _p(pts), _p(tc), texname.encode()))
+
+    def add_multi_textured_object(self, name, points, texcoord, tri_tex, tex_names, textures):
+        """Object whose triangles use several textures (house.obj): tri_tex[i] indexes tex_names / textures, -1 = untextured."""
+        pts, tc = _f(points).reshape(-1, 12), _f(texcoord).reshape(-1, 6)
+        tt = np.ascontiguousarray(tri_tex, np.int32)
+        for nm, tex in zip(tex_names, textures):
+            tex = np.ascontiguousarray(tex, np.uint8)
+            _ok(self.L.srth_om_add_texture(self.om, nm.encode(), tex.shape[1], tex.shape[0], _p(tex, _u8p)))
+        _ok(self.L.srth_om_add_multi_textured_object(self.om, name.encode(), pts.shape[0], _p(pts), _p(tc), _p(tt, _i32p), "\n".join(tex_names).encode()))
 
     def clone(self, src, dst): _ok(self.L.srth_om_clone(self.om, src.encode(), dst.encode()))
     def setColor(self, name, rgb): _ok(self.L.srth_om_set_color(self.om, name.encode(), *[float(x) for x in rgb]))

@@ -36,7 +36,11 @@ import scenes                              # noqa: E402
 
 M = po.RefMat
 BG = np.array(abi.REFERENCE_BACKGROUND, np.int32)
-REF_OBJ = {"cube": "cube.obj", "sphere": "sphere.obj", "bunny": "./obj/stanford-bunny.obj", "tree": "./obj/tree/tree.obj"}
+REF_OBJ = {"cube": "cube.obj", "sphere": "sphere.obj", "bunny": "./obj/stanford-bunny.obj", "tree": "./obj/tree/tree.obj",
+           "horse": "./obj/horse/horse.obj"}
+# house.obj (six textures) without the two triangles of its 'Plane' object, whose texture is a missing blob: the reference
+# null-derefs when such a triangle is hit (simple_raytracer.cpp:354-358), so no golden can contain them
+REF_OBJ_MULTI = {"house_noplane": "./obj/house/house.obj"}
 
 
 def sha(a):
@@ -64,12 +68,37 @@ def export_mesh(key):
     return pts
 
 
+def export_multi_textured_mesh(key):
+    """A mesh whose triangles use several textures, as the reference's loader produced it (per-triangle textureName), minus the
+    triangles whose texture failed to load."""
+    name = REF_OBJ_MULTI[key]
+    s = po.RefScene(); s.load_obj(name)
+    pts = s.points(name)
+    tc, col, ht, nrm = s.tri_attrs(name)
+    tn = [s.tri_texture_name(name, i) for i in range(len(pts))]
+    loaded = {n: s.texture(n) for n in sorted(set(tn)) if n}
+    keep = np.array([(not n) or loaded[n] is not None for n in tn])
+    names = [n for n in loaded if loaded[n] is not None]
+    tri_tex = np.array([names.index(n) if n in names else -1 for n in tn], np.int32)[keep]
+    pts, tc = pts[keep], tc[keep]
+    print(f"   {key}: {len(keep)} triangles loaded, {int((~keep).sum())} dropped (texture missing), {len(names)} textures")
+    assert np.all(pts[..., 3] == 1.0) and tc.max() < 65536 and np.all(tc == np.floor(tc))
+    v = pts[..., :3].reshape(-1, 3)
+    uv, inv = np.unique(v, axis=0, return_inverse=True)
+    f = inv.astype(np.int32).reshape(-1, 3)
+    assert np.array_equal(uv[f], pts[..., :3])
+    np.savez_compressed(os.path.join(HERE, "meshes", key + ".npz"), v=uv.astype(np.float32), f=f, texcoord=tc.astype(np.uint16),
+                        tri_tex=tri_tex.astype(np.int8), texture_names=np.array(names), **{f"texture_{k}": loaded[n] for k, n in enumerate(names)})
+    return {"points": pts, "texcoord": tc, "tri_tex": tri_tex, "texture_names": names, "textures": [loaded[n] for n in names]}
+
+
 class RefBuilder:
     """Replays a recipe on the reference's ObjectManager; 'load' goes through the REAL loader."""
     def __init__(self, real_loader=True, meshes=None):
         self.s = po.RefScene(); self.real = real_loader; self.meshes = meshes or {}
     def add_object(self, name, pts): self.s.add_object(name, pts)
     def add_textured_object(self, name, pts, tc, texname, tex): self.s.add_textured_object(name, pts, tc, texname, tex)
+    def add_multi_textured_object(self, name, pts, tc, tt, names, texs): self.s.add_multi_textured_object(name, pts, tc, tt, names, texs)
     def clone(self, a, b): self.s.clone(a, b)
     def set_color(self, n, c): self.s.set_color(n, c)
     def set_props(self, n, p): self.s.set_props(n, p)
@@ -116,7 +145,19 @@ def outputs(s, flat, light3, W, H, n_lights, full):
     return out
 
 
-def make_scene(name, recipe, meshes, renders, textures=None, prebuilt=None, compact=False):
+def band_outputs(s, light3, W, H, n_lights, y0, y1):
+    """Reference outputs for rows [y0, y1) of a W x H frame (a whole 3840x2160 frame with 64 light samples would be hours of
+    reference time): keys band_<W>x<H>_L<n>_y<y0>_<y1>_*; same contents as outputs()."""
+    hit, t, tone, lin = s.trace(W, H, np.array(light3, np.float32), n_lights, rows=(y0, y1))
+    q = np.clip((tone * np.float32(255.0)).astype(np.int32), 0, 255)
+    rgb8 = q.copy(); rgb8[q.sum(-1) == 0] = BG
+    pre = f"band_{W}x{H}_L{n_lights}_y{y0}_{y1}_"
+    print(f"   {W}x{H} rows {y0}..{y1} L={n_lights}: {int((hit >= 0).sum())} hit px")
+    return {pre + "hit_id": hit, pre + "rgb8": rgb8.astype(np.uint8), pre + "sha_t": np.array(sha(t)), pre + "sha_lin": np.array(sha(lin)),
+            pre + "sub_stride": np.array(61), pre + "sub_t": t.reshape(-1)[::61].copy(), pre + "sub_lin": lin.reshape(-1, 3)[::61].copy()}
+
+
+def make_scene(name, recipe, meshes, renders, textures=None, prebuilt=None, compact=False, bands=()):
     print("scene", name)
     s = prebuilt if prebuilt is not None else replay_on_ref(recipe, meshes, real_loader=True)
     flat = s.export(textures=textures)
@@ -140,9 +181,12 @@ def make_scene(name, recipe, meshes, renders, textures=None, prebuilt=None, comp
         d = flat.to_npz_dict()
     d["recipe"] = np.array(recipe.to_json() if recipe is not None else "")
     d["light"] = np.array(recipe.light if recipe is not None else renders[0][4], np.float32)
+    import time
     for (W, H, nl, full, *rest) in renders:
         light3 = recipe.light if recipe is not None else rest[0]
         d.update(outputs(s, flat, light3, W, H, nl, full))
+    for (W, H, nl, y0, y1) in bands:
+        d.update(band_outputs(s, recipe.light, W, H, nl, y0, y1))
     np.savez_compressed(os.path.join(HERE, f"scene_{name}.npz"), **d)
     print("   ->", os.path.getsize(os.path.join(HERE, f"scene_{name}.npz")) // 1024, "KiB;",
           flat.n_objects, "objects", flat.n_nodes, "nodes", flat.n_tris, "tris; order", flat.names)
@@ -402,10 +446,20 @@ def make_polygons():
     print("polygons.npz", len(faces), "faces ->", len(pts), "triangles")
 
 
+def make_k4(meshes=None):
+    """BASELINE configs[3] at its own shape: the composite scene with horse and house, 64 light samples
+    (lightAmount = 64, softShadow:348,366-383): a 320x180 frame in full and a band of scanlines of the 3840x2160 frame."""
+    if meshes is None:
+        meshes = {k: export_mesh(k) for k in ("cube", "bunny", "tree", "horse")}
+        meshes["house_noplane"] = export_multi_textured_mesh("house_noplane")
+    make_scene("k4", scenes.composite_k4(M, 0.0), meshes, [(320, 180, 64, False), (160, 90, 9, True)], compact=True,
+               bands=[(3840, 2160, 64, 1000, 1008), (3840, 2160, 64, 1120, 1128)])
+
+
 def main():
     assert po.ref_available(), "build oracle/_ref first: make -C oracle ref"
-    if len(sys.argv) > 1 and sys.argv[1] in ("jpeg", "polygons"):
-        (make_jpeg if sys.argv[1] == "jpeg" else make_polygons)()
+    if len(sys.argv) > 1 and sys.argv[1] in ("jpeg", "polygons", "k4"):
+        {"jpeg": make_jpeg, "polygons": make_polygons, "k4": make_k4}[sys.argv[1]]()
         return
     make_jpeg()
     make_polygons()
@@ -423,6 +477,8 @@ def main():
     tex = meshes["tree"]["texture_name"]
     make_scene("main_nocats", scenes.main_scene_no_cats(M, 0.0), meshes, [(600, 400, 1, False), (150, 100, 4, True)],
                textures={"./obj/tree/tree.obj": tex, "./obj/tree/tree.obj1": tex, "./obj/tree/tree.obj2": tex}, compact=True)
+    meshes["house_noplane"] = export_multi_textured_mesh("house_noplane")
+    make_k4(meshes)
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-SCENES = ["cube", "sphere", "cubes4_a0", "cubes4_a40", "spheres6", "cube_ground", "ground_bunny", "texquad", "main_nocats"]
+SCENES = ["cube", "sphere", "cubes4_a0", "cubes4_a40", "spheres6", "cube_ground", "ground_bunny", "texquad", "main_nocats", "k4"]
 
 
 def sha(a):
@@ -52,6 +52,21 @@ class GoldenScene:
                     assert sha(getattr(f, k)) == str(self.z[key]), f"host mirror's {k} differs from the reference's export"
             self._flat = f
         return self._flat
+
+    @property
+    def bands(self):
+        """(W, H, L, y0, y1) of the scanline-band outputs (frames too big for a whole reference render)."""
+        return sorted({tuple(int(x) for x in m.groups())
+                       for m in (re.match(r"band_(\d+)x(\d+)_L(\d+)_y(\d+)_(\d+)_hit_id$", k) for k in self.z.files) if m})
+
+    def band_out(self, W, H, L, y0, y1, key):
+        return self.z[f"band_{W}x{H}_L{L}_y{y0}_{y1}_{key}"]
+
+    def band_params(self, W, H, L, y0, y1, **kw):
+        """srt_params that render exactly rows [y0, y1): one scanline block (y0 must be a multiple of the band height)."""
+        rows = y1 - y0
+        assert y0 % rows == 0
+        return abi.make_params(W, H, abi.light_staircase(self.light, L), block_rows=rows, block_first=y0 // rows, block_stride=10 ** 6, **kw)
 
     def out(self, W, H, L, key):
         k = f"{W}x{H}_L{L}_{key}"

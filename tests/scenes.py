@@ -57,7 +57,9 @@ def apply_op(builder, op, meshes):
     k = op[0]
     if k == "load":
         m = meshes[op[2]]
-        if isinstance(m, dict): builder.add_textured_object(op[1], m["points"], m["texcoord"], m["texture_name"], m["texture"])
+        if isinstance(m, dict) and "tri_tex" in m:
+            builder.add_multi_textured_object(op[1], m["points"], m["texcoord"], m["tri_tex"], m["texture_names"], m["textures"])
+        elif isinstance(m, dict): builder.add_textured_object(op[1], m["points"], m["texcoord"], m["texture_name"], m["texture"])
         else: builder.add_object(op[1], m)
     elif k == "clone": builder.clone(op[1], op[2])
     elif k == "color": builder.set_color(op[1], op[2])
@@ -166,6 +168,30 @@ def main_scene_no_cats(M, angle=0.0):
     return r
 
 
+def composite_k4(M, angle=0.0):
+    """BASELINE config 4: the composite scene of the reference's main() (ground cube :554-559, bunny :583-591,
+    three textured trees :594-618) with the assets that are present standing in for the two cats (cat.obj is a missing blob): the
+    horse in cat 0's place (:567-572, same rotations) and the house -- without its 'Plane' object, whose texture is a missing blob
+    -- near cat 1's (:574-579).  Like the cats, the horse gets specular strength 0 (:564); each object goes into view space."""
+    r = main_scene_no_cats(M, angle)
+    inv = _orbit_view(M, 50.0, angle, -50.0, 30.0)
+    r.load("./obj/horse/horse.obj", "horse")
+    r.props("./obj/horse/horse.obj", (0.2, 0.0, 15.0))
+    r.transform("./obj/horse/horse.obj", M.scale(0.0125, 0.0125, 0.0125))
+    r.transform("./obj/horse/horse.obj", M.rotx(M.radians(-90.0)))
+    r.transform("./obj/horse/horse.obj", M.roty(M.radians(125.0)))
+    r.transform("./obj/horse/horse.obj", M.translate(25.0, -25.0, -16.0))
+    r.transform("./obj/horse/horse.obj", inv)
+    r.bvh("./obj/horse/horse.obj")
+    r.load("./obj/house/house.obj", "house_noplane")
+    r.transform("./obj/house/house.obj", M.scale(0.03, 0.03, 0.03))
+    r.transform("./obj/house/house.obj", M.rotx(M.radians(180.0)))
+    r.transform("./obj/house/house.obj", M.translate(14.0, -25.0, 20.0))
+    r.transform("./obj/house/house.obj", inv)
+    r.bvh("./obj/house/house.obj")
+    return r
+
+
 def cube_over_ground(M):
     """BASELINE config 2 ('cube.obj, 1920x1080, Phong + 1 hard-shadow ray'): a single object can never
     be shadowed (shadowIntersection:331), so the cube of :714-717 stands over a second ground cube
@@ -258,6 +284,10 @@ def mesh_points(npz):
     v, f = npz["v"], npz["f"]
     pts = np.ones((f.shape[0], 3, 4), np.float32)
     pts[:, :, :3] = v[f]
+    if "tri_tex" in npz.files:      # several textures per object (house.obj): per-triangle index, -1 = untextured
+        names = [str(x) for x in npz["texture_names"]]
+        return {"points": pts, "texcoord": npz["texcoord"].astype(np.float32), "tri_tex": npz["tri_tex"].astype(np.int32),
+                "texture_names": names, "textures": [npz[f"texture_{k}"] for k in range(len(names))]}
     if "texcoord" in npz.files:
         return {"points": pts, "texcoord": npz["texcoord"].astype(np.float32), "texture_name": str(npz["texture_name"]),
                 "texture": npz["texture"]}

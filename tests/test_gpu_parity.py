@@ -81,6 +81,28 @@ def test_gpu_matches_oracle_and_work_counts(srt, oracle, name, W, H, L):
     assert o2["stats"]["node_tests"] == 0
 
 
+@pytest.mark.parametrize("flags", [0, abi.SRT_FLAG_COUNT_WORK])
+def test_k4_bands_at_full_size(srt, oracle, flags):
+    """BASELINE configs[3] at its own shape: composite scene (ground, bunny, three trees, horse, house: 223,855 triangles, 8
+    textures), 3840x2160, 64 light samples.  Two bands of scanlines through the shipped pipeline for that light count (node-queue
+    closest hit, quadrant list, packet shadow kernel with the samples cut into four chunks, shading) against what the compiled
+    reference rendered for the same rows; the counting build's work counts against the oracle's."""
+    g, ds = device_scene(srt, "k4")
+    for (W, H, L, y0, y1) in g.bands:
+        p = g.band_params(W, H, L, y0, y1, flags=flags)
+        o = ds.render(p)
+        assert np.array_equal(o["hit_id"], g.band_out(W, H, L, y0, y1, "hit_id")), "closest-hit ids differ from the reference"
+        assert gu.sha(o["t"]) == str(g.band_out(W, H, L, y0, y1, "sha_t"))
+        check_rgb8(o["rgb8"], g.band_out(W, H, L, y0, y1, "rgb8"), max_frac=1e-3)
+        st = int(g.band_out(W, H, L, y0, y1, "sub_stride"))
+        assert np.abs(o["rgb_linear"].reshape(-1, 3)[::st] - g.band_out(W, H, L, y0, y1, "sub_lin")).max() < TOL_LINEAR * 64
+        if flags & abi.SRT_FLAG_COUNT_WORK:
+            c = oracle.render(g.flat, p)
+            for k in ("node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow", "shadow_rays"):
+                assert o["stats"][k] == c["stats"][k], k
+            assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max()))
+
+
 def test_scanline_blocks_reassemble_bitwise(srt):
     """Block-cyclic scanline tiling (the multi-GPU split) never changes a pixel."""
     g, ds = device_scene(srt, "ground_bunny")
@@ -126,7 +148,7 @@ def test_deep_soup_rows_match_oracle(srt, oracle):
     p = abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK, **kw)
     c = oracle.render(flat, p)
     assert c["hit_id"].shape[0] == 8 and (c["hit_id"] >= 0).mean() > 0.1
-    for variant in (0, 3, 6):
+    for variant in (0, 3, 6, 21, 22, 23, 24):
         o = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8), **kw))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
@@ -190,7 +212,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 18])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 18, 20, 21, 22, 23, 24])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -228,7 +250,7 @@ def test_big_leaves_and_signed_zero_t(srt, oracle):
                          obj_root=[0], tri_points=pts, tri_obj=np.zeros(n, np.int32),
                          obj_color=[[0.8, 0.6, 0.2]], obj_material=[[0.2, 0.5, 15.0]])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 10):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 10, 22):
         p = abi.make_params(96, 64, [[100.0, -200.0, 50.0]], flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
@@ -358,7 +380,7 @@ def test_many_objects_empty_objects_and_no_lights(srt, oracle):
     flat = host.build_flat_scene(recipe, meshes)
     assert flat.n_objects == 40 and 0 in list(flat.node_count[flat.node_left < 0])
     ds = srt.DeviceScene(flat)
-    for variant in (0, 3, 6, 10):
+    for variant in (0, 3, 6, 10, 21, 22):
         p = abi.make_params(203, 117, abi.light_staircase(recipe.light, 2), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8))
         o = ds.render(p); c = oracle.render(flat, p)
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
@@ -451,7 +473,7 @@ def test_adversarial_scenes_match_oracle(srt, oracle, seed):
     p = abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK)
     c = oracle.render(flat, p)
     assert (c["hit_id"] >= 0).sum() > 200
-    for variant in (0, 4, 3, 6):
+    for variant in (0, 4, 3, 6, 21, 22):
         o = ds.render(abi.make_params(W, H, abi.light_staircase(recipe.light, L), focal=focal, flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8)))
         assert np.array_equal(o["hit_id"], c["hit_id"]), f"variant {variant}: {int((o['hit_id'] != c['hit_id']).sum())} hit ids differ"
         assert np.array_equal(bits(o["t"]), bits(c["t"]))
@@ -489,12 +511,42 @@ def test_many_objects_and_light_groups(srt, oracle, n_obj, L):
     lights = abi.light_staircase(recipe.light, L)
     c = oracle.render(flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
     assert (c["hit_id"] >= 0).sum() > 300
-    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8, 17 << 8, 18 << 8):   # shipped (fused below 8 samples, else chunked), counting build, unfused, fused with 64 rays in flight
+    # shipped (fused below 8 samples, else node-queue closest hit + packet shadow rays), counting build, unfused, fused with 64 rays in
+    # flight, XCD row deal, round-1 chunked shadow launch, packet shadow rays at any count, packet closest hit + packet shadow rays
+    for flags in (0, abi.SRT_FLAG_COUNT_WORK, 10 << 8, 17 << 8, 18 << 8, 20 << 8, 21 << 8, 22 << 8, 23 << 8, (22 << 8) | abi.SRT_FLAG_COUNT_WORK):
         o = ds.render(abi.make_params(W, H, lights, flags=flags))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
         check_rgb8(o["rgb8"], c["rgb8"])
         assert o["stats"]["shadow_rays"] == c["stats"]["shadow_rays"]
+
+
+@pytest.mark.parametrize("name,W,H", [("ground_bunny", 150, 100), ("main_nocats", 150, 100)])
+@pytest.mark.parametrize("L", [9, 64])
+def test_many_light_samples_on_deep_trees(srt, oracle, name, W, H, L):
+    """8+ light samples on scenes with deep hierarchies (bunny: depth 14; the reference's main() scene: 177 k triangles, textured
+    trees), every launch form that serves them: the shipped pipeline (node-queue closest hit + packet shadow kernel with the
+    samples cut over blockIdx.z), the fused kernel with 64 shadow rays in flight (17), the round-1 chunked node-queue shadow launch
+    (20), packet shadow rays behind the unfused closest hit (21), the all-packet pipeline (22) and the counting builds; hit ids and
+    t bitwise, colours and work counts against the oracle."""
+    g, ds = device_scene(srt, name)
+    lights = abi.light_staircase(g.light, L)
+    c = oracle.render(g.flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
+    assert (c["hit_id"] >= 0).sum() > 1000
+    for flags in (0, 17 << 8, 20 << 8, 21 << 8, 22 << 8, abi.SRT_FLAG_COUNT_WORK, (22 << 8) | abi.SRT_FLAG_COUNT_WORK):
+        o = ds.render(abi.make_params(W, H, lights, flags=flags))
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
+        assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
+        check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+        assert o["stats"]["shadow_rays"] == c["stats"]["shadow_rays"]
+        if flags & abi.SRT_FLAG_COUNT_WORK:
+            for k in ("node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow"):
+                assert o["stats"][k] == c["stats"][k], (flags, k)
+    if L == 9:      # supersampling on top of the chunked launches, no counting flag (spp > 1 is oracle-pinned only, SURVEY.md R4)
+        p4 = abi.make_params(W, H, lights, spp=4)
+        o4 = ds.render(p4); c4 = oracle.render(g.flat, p4)
+        assert np.array_equal(o4["hit_id"], c4["hit_id"]) and np.abs(o4["rgb_linear"] - c4["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c4["rgb_linear"]).max()))
+        check_rgb8(o4["rgb8"], c4["rgb8"], max_frac=1e-3)
 
 
 def test_c_abi_from_plain_c(srt, oracle, tmp_path):

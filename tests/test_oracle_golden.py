@@ -81,6 +81,21 @@ def test_scene_matches_reference(oracle, name, W, H, L):
     assert st["shadow_rays"] == st["hit_rays"] * L and st["primary_rays"] == W * H
 
 
+def test_k4_bands_at_full_size_match_reference(oracle):
+    """BASELINE configs[3] at its own shape (3840x2160, 64 light samples, composite scene with horse and house): two bands of
+    scanlines the compiled reference rendered (a whole frame would be hours of reference time)."""
+    g = gu.GoldenScene("k4")
+    assert g.flat.n_objects == 7 and g.flat.n_tris == 223855 and g.flat.n_textures == 8
+    assert len(g.bands) == 2
+    for (W, H, L, y0, y1) in g.bands:
+        assert (W, H, L) == (3840, 2160, 64)
+        o = oracle.render(g.flat, g.band_params(W, H, L, y0, y1))
+        assert np.array_equal(o["hit_id"], g.band_out(W, H, L, y0, y1, "hit_id"))
+        assert np.array_equal(o["rgb8"], g.band_out(W, H, L, y0, y1, "rgb8"))
+        assert gu.sha(o["t"]) == str(g.band_out(W, H, L, y0, y1, "sha_t")) and gu.sha(o["rgb_linear"]) == str(g.band_out(W, H, L, y0, y1, "sha_lin"))
+        assert (o["hit_id"] >= 0).sum() > 3000
+
+
 def test_scanline_blocks_tile_the_frame(oracle):
     """Block-cyclic scanline ownership (multi-GPU tiling): any split reassembles to the whole frame."""
     g = gu.GoldenScene("cubes4_a0")
