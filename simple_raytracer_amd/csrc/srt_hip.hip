@@ -483,7 +483,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
-    if (force_nq || variant == 25 || variant == 26) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records by scalar loads (A/B)
+    if (force_nq || variant == 25) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -587,12 +587,11 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
         if (pk_shadow) {
             // a fixed number of waves pull units (the shadow rays of 64 / n_lights pixels) from the quadrant list: no grid over the image
-            const uint64_t max_entries = (uint64_t)n_tiles * 4u;
-            const uint32_t wgs = (uint32_t)(max_entries < (uint64_t)s->n_cu * 8 ? max_entries : (uint64_t)s->n_cu * 8);
-            const uint32_t lc_shape = (p->flags >> 8 & 0xffu) == 26 ? 4u : 8u;       // walk shape: 8 pixels x 8 samples; 26: 16 pixels x 4 samples (A/B)
-            if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);
-            else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);   // records by scalar loads (A/B)
-            else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr, lc_shape);
+            const uint64_t max_units = (uint64_t)n_tiles * 4u * 2u * ((p->n_lights + 7) / 8);
+            const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * 8 ? max_units / 4 + 1 : (uint64_t)s->n_cu * 8);
+            if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
+            else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // records through LDS windows (A/B)
+            else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         } else if (p->n_lights && !fused) {
             if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64, 6>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,

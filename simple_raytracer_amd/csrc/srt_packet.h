@@ -45,7 +45,7 @@ __device__ __forceinline__ bool packet_slab(V3 o, V3 d, RayRcp rc, const DevNode
 // object, which the walk jumps over (the reference walks it and discards the result, :328/:331).  Returns "shadowed".
 template <bool COUNT, bool FILTER>
 __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self,
-                                               unsigned long long& n_node, unsigned long long& n_tri) {
+                                               unsigned long long& n_node, unsigned long long& n_tri, unsigned long long* diag = nullptr) {
     const uint32_t N = s.n_nodes;
     const RayRcp rc = ray_rcp(rd);
     uint32_t n = valid ? 0u : N;
@@ -53,7 +53,8 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
     bool flag = false;
     uint32_t i = wave_min_u32(n);
     while (i < N) {
-        const DevNode nd = s.nodes[i];                          // wave-uniform index: scalar loads
+        const DevNode nd = s.nodes[i];                          // wave-uniform index: one request per wave
+        if (COUNT && diag) diag[0]++;
         const bool act = n == i;
         bool pass = false;
         if (act) {
@@ -65,6 +66,7 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
             const uint32_t first = (uint32_t)nd.leaf >> LEAF_SHIFT, cnt = (uint32_t)nd.leaf & LEAF_MAX;
             bool todo = pass;
             for (uint32_t k = 0; k < cnt && __ballot(todo); k++) {
+                if (COUNT && diag) diag[2]++;
                 const DevTri tr = s.tris[first + k];            // wave-uniform
                 if (todo) {
                     if (COUNT) n_tri++;
@@ -278,129 +280,99 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
 // tiles (x light-sample chunks) is bound by workgroup dispatch, not by work (measured: 2.07 M waves launched, 23 % of the wave
 // slots occupied), and a tile in a tree crown is a long workgroup.  So the closest-hit kernels append every quadrant with a
 // hit to a list -- 64 shard lists with their own counters, one atomic per wave with hits -- and this kernel is a fixed-size
-// grid of workgroups that pull quadrants from it: entry e belongs to fetch shard e % 64, a workgroup takes the next entry of
-// its home shard with one atomic (issued one entry ahead) and moves on to shards that still have entries when its own is empty.
+// grid whose WAVES pull work units from it, every wave on its own (no workgroup-level synchronisation: a quadrant in a tree
+// crown is 16 long walks, and they spread over 16 waves anywhere on the chip).
 //
-// Wave 0 unpacks the quadrant once (hit pixels -> shadow-ray origin d*t and own-object range, in LDS); then the four waves take
-// packet walks from it through an LDS counter.  A walk = 8 hit pixels x 8 consecutive light samples = at most 64 shadow rays that
-// stay close together all the way: 8 samples move the light by at most 9 units per axis on a ~600-unit lever, 8 neighbouring
-// pixels start within a unit of each other (measured against the alternatives: 64 samples of ONE pixel fan out over ~5 units
-// at the far side of the scene and part ways in the tree crowns -- 1.9 ms on the K4 shape against 0.9 for 16 pixels x 4
-// samples).  A quadrant in a tree crown with 64 samples is 16 long walks: shared by four waves it is four walks
-// long, not sixteen.
+// A unit is ONE packet walk: (quadrant, group of 8 hit pixels, 8 consecutive light samples) = at most 64 shadow rays that stay
+// close together all the way: 8 samples move the light by at most 9 units per axis on a ~600-unit lever, 8 neighbouring pixels
+// start within a unit of each other.  Measured alternatives (K4 shape): the 64 samples of ONE pixel fan out over
+// ~5 units at the far side of the scene and part ways in the tree crowns; 16 pixels x 4 samples start on too many different
+// leaves.  The counting build reports the shape of the walks: 7 steps on average (6 of them the roots of the other objects),
+// 49 of 64 lanes active per step.
+// Units are dealt dynamically: unit u belongs to fetch shard u % 64; a wave takes the next unit of its home shard with one
+// atomic (issued one unit ahead, so its round trip hides behind the walk) and moves on to shards that still have work when
+// its own is empty -- with static striding the launch lasted as long as the wave that happened to own a tree crown.
 // Result, pixel-major: per hit pixel one u64 per 64 light samples, bit = sample; a walk owns one BYTE of a pixel's word (the rays
-// of a pixel are 8 consecutive lanes: a byte of the ballot), so there are no atomics.
+// of a pixel are 8 consecutive lanes: a byte of the ballot), so there are no atomics on the result.
 // =================================================================================================
-struct PkEntryLds {
-    float4 pix_o[16];                    // per hit rank: shadow-ray origin d*t (:326), pixel index (w) as bits
-    int2 pix_self[16];                   // per hit rank: node range of the hit object
-    uint32_t n_walks, next_walk, n_hit, live;
-};
-
-// qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) entries handed out per fetch shard; counters
+// qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) units handed out per fetch shard; counters
 // QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
 template <bool COUNT, bool FILTER, bool WINDOWS>
-__global__ __launch_bounds__(256) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
+__global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                    uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
-                                                   unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters, uint32_t lc_shape) {
-    __shared__ PkEntryLds E;
+                                                   unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
     __shared__ PkWindows win_all[4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t nbase = 0x80000000u, tbase = 0x80000000u;                   // window bases (sentinel: nothing loaded); the windows outlive a walk
     const uint32_t tiles_x = (p.W + 7u) / 8u;
     const uint32_t n_lch = (p.n_lights + 63u) >> 6;                       // u64 words per pixel
-    const uint32_t n_lc8 = (p.n_lights + 7u) >> 3;                        // chunks of 8 light samples
-    // walk shape: PG pixels x LC consecutive light samples, PG * LC = 64; a grab = one byte of the pixels' words = 8 samples = 8 / LC walks
-    const uint32_t LC = lc_shape, PG = 64u / LC;
-    const uint32_t pr = lane / LC, lg = lane - pr * LC;                   // this lane's pixel slot and light sample within a walk
-    // wave 0 deals the entries: prefix sum over the shard list lengths (lane k holds shard k), fetch counters, prefetched number
-    uint32_t cnt = 0, incl = 0, n_entries = 0, home = blockIdx.x & (QL_SHARDS - 1), k_next = 0;
-    uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
-    if (wave == 0) {
-        cnt = qcount[lane * QL_STRIDE];
-        cnt = cnt < qcap ? cnt : qcap;
-        incl = cnt;
+    const uint32_t n_lc8 = (p.n_lights + 7u) >> 3;                        // chunks of 8 light samples = bytes per pixel
+    const uint32_t upe = 2u * n_lc8;                                      // units per entry: two groups of 8 hit ranks x the chunks
+    const uint32_t pr = lane >> 3, lg = lane & 7u;                        // this lane's pixel slot and light sample within a walk
+    // prefix sum over the shard list lengths: lane k holds shard k
+    uint32_t cnt = qcount[lane * QL_STRIDE];
+    cnt = cnt < qcap ? cnt : qcap;
+    uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
-        n_entries = (uint32_t)__shfl((int)incl, 63, 64);
-        if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
-    }
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
+    const uint32_t n_entries = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t n_units = n_entries * upe;
+    uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
+    uint32_t home = (blockIdx.x * 4u + wave) & (QL_SHARDS - 1);
+    uint32_t k_next = 0;
+    if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
     for (;;) {
-        if (wave == 0) {
-            bool live = true;
-            uint32_t e = 0;
-            for (;;) {
-                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
-                e = k * QL_SHARDS + home;
-                if (e < n_entries) break;
-                // home shard empty: look (agent-scope loads, the counters only grow) for a shard that still has entries, next after home
-                const uint32_t seen = __hip_atomic_load(fetch + lane * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long open = __ballot((unsigned long long)seen * QL_SHARDS + lane < (unsigned long long)n_entries);
-                if (!open) { live = false; break; }
-                const unsigned long long rot = home == 63u ? open : ((open >> (home + 1u)) | (open << (63u - home)));      // bit j = shard home + 1 + j
-                home = (home + 1u + (uint32_t)__builtin_ctzll(rot)) & (QL_SHARDS - 1);
-                if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
-            }
-            if (live) {
-                if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);    // the next entry's number: in flight during this one
-                const unsigned long long above = __ballot(incl > e);             // first shard list whose inclusive prefix exceeds e
-                const uint32_t shard = (uint32_t)__builtin_ctzll(above);
-                const uint32_t excl = (uint32_t)__shfl((int)(incl - cnt), (int)shard, 64);
-                const uint2 ent = reinterpret_cast<const uint2*>(qlist)[(size_t)shard * qcap + (e - excl)];      // wave-uniform
-                const uint32_t hm = ent.y & 0xffffu, nh = (uint32_t)__popc(hm);
-                const uint32_t tile_index = ent.x >> 2, q = ent.x & 3u;
-                const uint32_t by = tile_index / tiles_x, bx = tile_index - by * tiles_x;
-                if (lane < 16 && ((hm >> lane) & 1u)) {                           // lanes < 16: bit = y * 4 + x inside the quadrant
-                    const uint32_t px = bx * 8u + (q & 1u) * 4u + (lane & 3u), r = by * 8u + (q >> 1) * 4u + (lane >> 2);
-                    const uint32_t pix = r * p.W + px;
-                    const int32_t id = hit_id[pix];
-                    const float t = t_in[pix];
-                    const V3 d = primary_dir(p, px, image_row(p, r));
-                    const V3 so = d * t;                                          // :326
-                    const uint32_t rank = (uint32_t)__popc(hm & ((1u << lane) - 1u));
-                    E.pix_o[rank] = make_float4(so.x, so.y, so.z, __uint_as_float(pix));
-                    E.pix_self[rank] = s.obj_range[s.tri_obj[id]];
-                }
-                if (lane == 0) { E.n_hit = nh; E.n_walks = ((nh + PG - 1u) / PG) * n_lc8; E.next_walk = 0u; }
-            }
-            if (lane == 0) E.live = live ? 1u : 0u;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
+        const uint32_t u = k * QL_SHARDS + home;
+        if (u >= n_units) {
+            // home shard empty: look (agent-scope loads, the counters only grow) for a shard that still has units, next after home
+            const uint32_t seen = __hip_atomic_load(fetch + lane * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long open = __ballot((unsigned long long)seen * QL_SHARDS + lane < (unsigned long long)n_units);
+            if (!open) break;
+            const unsigned long long rot = home == 63u ? open : ((open >> (home + 1u)) | (open << (63u - home)));      // bit j = shard home + 1 + j
+            home = (home + 1u + (uint32_t)__builtin_ctzll(rot)) & (QL_SHARDS - 1);
+            if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
+            continue;
         }
-        __syncthreads();
-        if (!E.live) break;
-        const uint32_t n_walks = E.n_walks, nh = E.n_hit;
-        for (;;) {
-            uint32_t wk = 0;
-            if (lane == 0) wk = atomicAdd(&E.next_walk, 1u);
-            wk = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk);
-            if (wk >= n_walks) break;
-            const uint32_t g = wk / n_lc8, lc = wk - g * n_lc8;                  // pixel group (PG hit ranks), byte = chunk of 8 light samples
-            const uint32_t rank = g * PG + pr;
-            V3 so = mk(0.f, 0.f, 0.f);
-            int2 self = make_int2(-1, -1);
-            uint32_t pix = 0;
-            if (rank < nh) {
-                const float4 po = E.pix_o[rank];
-                self = E.pix_self[rank];
-                pix = __float_as_uint(po.w);
-                so = mk(po.x, po.y, po.z);
-            }
-            uint32_t byte = 0;
-            for (uint32_t half = 0; half < 8u; half += LC) {                      // LC = 8: one walk; LC = 4: one per nibble
-                const uint32_t l = lc * 8u + half + lg;
-                const bool valid = rank < nh && l < p.n_lights;
-                V3 sd = mk(0.f, 0.f, 1.f);
-                if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
-                if (COUNT) diag[4]++;
-                const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, win_all[wave], nbase, tbase, n_node, n_tri, diag)
-                                              : packet_any_hit<COUNT, FILTER>(s, valid, so, sd, self, n_node, n_tri);
-                const unsigned long long sm = __ballot(shadowed);
-                byte |= ((uint32_t)(sm >> (pr * LC)) & ((1u << LC) - 1u)) << half;
-            }
-            if (rank < nh && lg == 0 && lc * 8u < p.n_lights) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)byte;
+        if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);        // the next unit's number: in flight during this walk
+        // unit -> (chunk of 8 samples, entry, pixel group): consecutive units are different ENTRIES, so that the waves that
+        // start together do not all read the same quadrant
+        const uint32_t lc = u / (2u * n_entries), ue = u - lc * 2u * n_entries;
+        const uint32_t g = ue / n_entries, e = ue - g * n_entries;
+        const unsigned long long above = __ballot(incl > e);                 // first shard list whose inclusive prefix exceeds e
+        const uint32_t shard = (uint32_t)__builtin_ctzll(above);
+        const uint32_t excl = (uint32_t)__shfl((int)(incl - cnt), (int)shard, 64);
+        const uint2 ent = reinterpret_cast<const uint2*>(qlist)[(size_t)shard * qcap + (e - excl)];      // wave-uniform
+        const uint32_t hm = ent.y & 0xffffu, nh = (uint32_t)__popc(hm);
+        if (g * 8u >= nh) continue;                                          // at most 8 hit pixels in this quadrant: no second group
+        const uint32_t tile_index = ent.x >> 2, q = ent.x & 3u;
+        const uint32_t by = tile_index / tiles_x, bx = tile_index - by * tiles_x;
+        const uint32_t rank = g * 8u + pr, l = lc * 8u + lg;
+        const bool has_px = rank < nh;
+        const bool valid = has_px && l < p.n_lights;
+        V3 so = mk(0.f, 0.f, 0.f), sd = mk(0.f, 0.f, 1.f);
+        int2 self = make_int2(-1, -1);
+        uint32_t pix = 0;
+        if (has_px) {
+            // the rank-th set bit of the hit mask = this lane's pixel inside the quadrant (bit = y * 4 + x)
+            uint32_t m = hm;
+            for (uint32_t j = 0; j < rank; j++) m &= m - 1u;
+            const uint32_t bit = (uint32_t)__builtin_ctz(m);
+            const uint32_t px = bx * 8u + (q & 1u) * 4u + (bit & 3u), r = by * 8u + (q >> 1) * 4u + (bit >> 2);
+            pix = r * p.W + px;
+            const int32_t id = hit_id[pix];
+            const float t = t_in[pix];
+            self = s.obj_range[s.tri_obj[id]];
+            so = primary_dir(p, px, image_row(p, r)) * t;                     // :326
         }
-        __syncthreads();                                                          // wave 0 rewrites E
+        if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
+        if (COUNT) diag[4]++;
+        const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, win_all[wave], nbase, tbase, n_node, n_tri, diag)
+                                      : packet_any_hit<COUNT, FILTER>(s, valid, so, sd, self, n_node, n_tri, diag);
+        const unsigned long long sm = __ballot(shadowed);
+        if (valid && lg == 0) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)(sm >> (pr * 8u));
     }
     if (COUNT) {
         wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri);
