@@ -2,9 +2,14 @@
 """bench.py -- Mrays/s (primary + shadow) of the HIP ray-trace path at 1920x1080 on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by torch.distributed.run,
-one rank per GPU over RCCL).  One "step" = one pass of the hot path over one frame: closest-hit kernel
-+ shadow/shade kernel over this rank's scanline blocks, then (N > 1) the framebuffer gather to rank 0.
-Prints ONE JSON line on rank 0.
+one rank per GPU over RCCL).  One "step" = one pass of the hot path over a batch of 36 frames (the reference's
+main() renders a 36-frame orbit per run): closest-hit (+ shadow rays) and shading kernels over this rank's part
+of every frame, then (N > 1) ONE gather of the framebuffer tiles to rank 0.  Prints ONE JSON line on rank 0.
+
+The line carries, beside the throughput: `parity` (the last rendered frame against the committed reference golden /
+the CPU oracle: BASELINE.json's metric names both halves), `roofline` (the bound is chosen from counters collected IN
+THIS RUN: three short rocprofv3 --pmc passes of this same script as child processes, --no-pmc skips them) and
+`cpu_baseline`.
 
 Workload (config.workload): BASELINE.json configs[2], the configuration the north_star quotes its
 target on: stanford-bunny over a ground slab, 1920x1080, 1 light sample; scene from
@@ -30,9 +35,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 NODE_BYTES, TRI_BYTES = 32, 36  # algorithmic bytes per slab test / Moller-Trumbore test
 BLOCK_ROWS = 8                  # scanline block size for the multi-GPU block-cyclic split
+BLOCK_COLS = 0                  # > 0: tiles of 8 x BLOCK_COLS pixels dealt in two dimensions (srt_params.block_cols); measured: no gain over whole-width blocks
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -56,18 +62,33 @@ def main():
                          "GPUs than ranks (ranks share devices, tiles are staged through host memory)")
     ap.add_argument("--emulate-split", default="", help="R/N: time rank R's share of an N-way scanline split on ONE GPU (no collective); "
                                                          "diagnostic for the strong-scaling ceiling, not a bench line")
-    ap.add_argument("--frame-groups", type=int, default=0,
-                    help="N > 1: the frames of a step are dealt to this many groups of ranks, and inside a group every frame is split "
-                         "by scanline blocks (1 = every frame split over all ranks).  Default: the largest divisor of N that divides "
-                         "--frames (36 frames: 2, 4, 4 groups at N = 2, 4, 8), because a whole or half frame fills the chip better "
-                         "than an eighth of one")
+    ap.add_argument("--frame-groups", type=int, default=1,
+                    help="N > 1: 1 (default, what north_star asks for) = every frame is tiled over ALL ranks; F > 1 (opt-in hybrid) = the "
+                         "frames of a step are dealt to F groups of ranks and only inside a group is a frame tiled -- that is frame-level "
+                         "replication, which flatters strong scaling and cannot apply to single long frames (K4, K5)")
+    ap.add_argument("--block-cols", type=int, default=BLOCK_COLS,
+                    help="N > 1: width of the tiles the scanline blocks are cut into (tile (bx, by) -> rank (bx + by) mod N); 0 = whole-width "
+                         "scanline blocks")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / valu come from profiles/traffic.json, labelled)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block")
     ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
-    args = ap.parse_args()
+    ap.add_argument("--no-soup", action="store_true",
+                    help="skip the second, short measurement the default workload adds: the 1 M-triangle soup at the same resolution and split "
+                         "(north_star asks for the 1 / 2 / 4 / 8-GPU curve on the soup; it is reported as `soup` beside the headline value)")
+    return ap.parse_args()
 
+
+_setup = None
+
+
+def setup(args):
+    """Process-wide initialisation, once: device, process group, native build."""
+    global _setup
+    if _setup is not None:
+        return _setup
     import torch
     import torch.distributed as dist
-    from simple_raytracer_amd import abi, build, lib
-    import golden_util as gu
+    from simple_raytracer_amd import build, lib
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,7 +112,17 @@ def main():
     if world > 1:
         dist.barrier()
     lib.load()
+    _setup = (rank, local_rank, world)
+    return _setup
 
+
+def measure(args):
+    """One workload, measured as the contract says.  Returns the JSON object on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from simple_raytracer_amd import abi, lib
+    import golden_util as gu
+    rank, local_rank, world = setup(args)
     W, H, L, B = args.width, args.height, args.lights, args.frames
     if args.workload == "soup":
         g = soup_workload(args.tris)
@@ -104,27 +135,28 @@ def main():
     from simple_raytracer_amd import tiling
     emu = [int(x) for x in args.emulate_split.split("/")] if args.emulate_split else None
     # frames of a step -> FG groups of ranks; scanline blocks of a frame -> the world / FG ranks of a group
-    FG = args.frame_groups if args.frame_groups > 0 else max(f for f in range(1, world + 1) if world % f == 0 and B % f == 0)
+    FG = max(1, args.frame_groups)
     if world % FG or B % FG:
         raise SystemExit(f"--frame-groups {FG} must divide --gpus {world} and --frames {B}")
     per_group = world // FG
     B_total, B = B, B // FG                      # B: frames THIS rank renders per step
     split_rank, split_world = (emu if emu else (rank % per_group, per_group))
-    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=args.variant << 8, spp=args.spp)
-    rows = scene.rows(p)
+    BC = args.block_cols if split_world > 1 else 0
+    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=args.variant << 8, spp=args.spp)
+    rows, Wl = scene.rows(p), scene.cols(p)
     dev = torch.device("cuda", local_rank)
-    hit = torch.empty((S, rows, W), dtype=torch.int32, device=dev)
-    tbuf = torch.empty((S, rows, W), dtype=torch.float32, device=dev)
-    lin = torch.empty((S, rows, W, 3), dtype=torch.float32, device=dev)
+    hit = torch.empty((S, rows, Wl), dtype=torch.int32, device=dev)
+    tbuf = torch.empty((S, rows, Wl), dtype=torch.float32, device=dev)
+    lin = torch.empty((S, rows, Wl, 3), dtype=torch.float32, device=dev)
     side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
     SLOTS = 2 if world > 1 else 1        # double-buffered tiles: the gather of step s overlaps the rendering of step s+1
     gather = tiling.FrameGather(W, H, BLOCK_ROWS if per_group > 1 else H, rank, world, dev, frames=B_total,
-                                stage_through_host=(args.backend == "gloo"), slots=SLOTS, frame_groups=FG)
+                                stage_through_host=(args.backend == "gloo"), slots=SLOTS, frame_groups=FG, block_cols=BC)
     if emu:
         assert world == 1
-        gather.tiles = [torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev)]
+        gather.tiles = [torch.zeros((B, rows, Wl, 3), dtype=torch.uint8, device=dev)]
         gather.tile = gather.tiles[0]
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
@@ -148,7 +180,7 @@ def main():
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
     graphs = None
     if not args.no_graph:        # (an odd number of renders per handle leaves the hit counters of replayed frames un-zeroed: only statistics nobody reads)
-        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING, spp=args.spp)
+        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING, spp=args.spp)
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
             graphs = []
@@ -204,13 +236,22 @@ def main():
     st = scene.sync()
     rgb8 = gather.tiles[0][0]
 
+    # buffers of the last eager (shipped-pipeline) frame, for the parity block: the counting launch below reuses them
+    keep = None
+    if rank == 0 and world == 1 and not emu and not args.no_parity:
+        keep = (hit[0].cpu().numpy().copy(), tbuf[0].cpu().numpy().copy(), lin[0].cpu().numpy().copy(), rgb8.cpu().numpy().copy())
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
-    pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride,
+    pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride, block_cols=p.block_cols,
                          flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8), spp=args.spp)
     scene.render_device(pc, stream=stream, hit_id=hit[0].data_ptr(), t=tbuf[0].data_ptr(), rgb_linear=lin[0].data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
+    pipeline = scene.pipeline
     rays_rank = sc["primary_rays"] + sc["shadow_rays"]        # of one of this rank's frames (its scanline blocks)
+    # ---- parity of the frame the timed region rendered last (rank 0, whole frames only) -------------------------------
+    parity = None
+    if rank == 0 and world == 1 and not emu and not args.no_parity:
+        parity = parity_block(g, args, W, H, L, lights, *keep)
     if world > 1:
         rr = torch.tensor([rays_rank / FG, sc["primary_rays"] / FG, sc["shadow_rays"] / FG], dtype=torch.float64,        # summed over ranks: one whole frame
                           device=dev if args.backend == "nccl" else "cpu")
@@ -228,29 +269,37 @@ def main():
             sc[k] = sc[k] // args.spp
         if args.spp > 1:        # the event pair around the traversal spans all sub-frames: per launch = / spp (includes the small shade / accumulate launches in between)
             st = dict(st); st["ms_primary"] = st["ms_primary"] / args.spp
-        pixels = W * rows
+        pixels = int(sc["primary_rays"]) // args.spp      # pixels of the image this rank renders
         hits, miss = sc["hit_rays"], pixels - sc["hit_rays"]
         items = hits * L
         # algorithmic bytes per launch: 32 B per slab test + 36 B per Moller-Trumbore test of the kernel's own
         # traversal + the per-pixel / per-item records each kernel must read and write
-        kern = {
-            "k_closest_hit_nq": dict(ms=st["ms_primary"],
-                                    bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"]
-                                    + 8 * pixels + 15 * miss),
-            "k_shadow_nq": dict(ms=st["ms_shadow"],
-                             bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8),
-            "k_shade_tile": dict(ms=st["ms_shade"], bytes=4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8),
-        }
-        if (args.variant == 0 and L < 8) or args.variant in (11, 17):      # closest hit + shadow rays in one launch (shipped below 8 light samples)
-            a, b = kern.pop("k_closest_hit_nq"), kern.pop("k_shadow_nq")
-            kern = {"k_trace_nq": dict(ms=st["ms_primary"] + st["ms_shadow"], bytes=a["bytes"] + b["bytes"]), **kern}
+        b_closest = NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"] + 8 * pixels + 15 * miss
+        b_shadow = NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 4 * pixels + 8 * hits + items // 8
+        b_shade = 4 * pixels + (4 + 12 + 4 + 15) * hits + items // 8
+        names = pipeline.split("+")                      # what the library launched, e.g. k_trace_nq+k_shade_tile
         if args.variant == 1:
             kern = {"k_closest_hit": dict(ms=st["ms_primary"], bytes=NODE_BYTES * sc["node_tests_primary"] + TRI_BYTES * sc["tri_tests_primary"] + 8 * pixels),
                     "k_shade": dict(ms=st["ms_shade"], bytes=NODE_BYTES * sc["node_tests_shadow"] + TRI_BYTES * sc["tri_tests_shadow"] + 12 * hits + 23 * pixels)}
+        elif names[0] == "k_trace_nq":                   # closest hit + shadow rays in one launch
+            kern = {"k_trace_nq": dict(ms=st["ms_primary"] + st["ms_shadow"], bytes=b_closest + b_shadow), "k_shade_tile": dict(ms=st["ms_shade"], bytes=b_shade)}
+        else:
+            kern = {names[0]: dict(ms=st["ms_primary"], bytes=b_closest)}
+            if len(names) == 3:
+                kern[names[1]] = dict(ms=st["ms_shadow"], bytes=b_shadow)
+            kern["k_shade_tile"] = dict(ms=st["ms_shade"], bytes=b_shade)
         dom = max(kern, key=lambda k: kern[k]["ms"])
-        achieved = kern[dom]["bytes"] / (kern[dom]["ms"] * 1e-3) / 1e9 if kern[dom]["ms"] > 0 else 0.0
+        dom_ms = kern[dom]["ms"]
+        effective = kern[dom]["bytes"] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # ---- counters of THIS run: three rocprofv3 --pmc passes of this script as child processes -------------------
+        pmc = None
+        if world == 1 and not args.no_pmc and not args.emulate_split:
+            pmc = collect_pmc(sys.argv[1:], dom)
+        if pmc is None and world == 1:
+            pmc = committed_pmc(args.workload, dom, W, H, L)
+        roof = roofline_block(dom, dom_ms, kern[dom]["bytes"], effective, pmc, g)
         out = {
-            "metric": "Mrays/sec (primary+shadow) at 1920x1080", "value": round(value, 3), "unit": "Mrays/s",
+            "metric": "Mrays/sec (primary+shadow) at 1920x1080; max per-pixel |dRGB| vs CPU ref", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
@@ -267,25 +316,44 @@ def main():
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
                        "parallelism": "1 GPU" if world == 1 else
                                       (f"the {B_total} frames of a step dealt to {FG} group(s) of {per_group} GPU(s); inside a group " +
-                                       (f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic" if per_group > 1 else "whole frames") +
+                                       ((f"tiles of {BLOCK_ROWS} x {BC} pixels, tile (bx, by) -> rank (bx + by) mod {per_group}" if BC else
+                                         f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic") if per_group > 1 else "whole frames") +
                                        "; one RCCL gather of all tiles per step, overlapped with the next step's rendering"),
                        "frames_per_step": B_total, "ms_per_frame": round(ms_step / B_total, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + f", {S} stream(s)",
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.workload, dom, W, H, L) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": kern[dom]["bytes"], "kernel_ms": round(kern[dom]["ms"], 5),
-                         "valu": measured_valu(args.workload, dom, W, H, L) if world == 1 else None,
-                         "note": "algorithmic bytes = 32 B x slab tests + 36 B x triangle tests (+ per-pixel output bytes) of the "
-                                 f"kernel's own traversal; the scene ({(g.flat.n_nodes * 32 + g.flat.n_tris * 96) / 1e6:.1f} MB of node and triangle records) is "
-                                 "L2 / Infinity-Cache resident, so this is an effective rate that can exceed the HBM peak"},
+            "roofline": roof,
             "kernels": {k: {"ms": round(v["ms"], 5), "algorithmic_bytes": v["bytes"]} for k, v in kern.items()},
         }
+        out["config"]["pipeline"] = pipeline
+        if parity is not None:
+            out["parity"] = parity
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, W, H, L, lights)
             if L == 1:
                 out["cpu_reference"] = cpu_reference(g, W, H)
+        return out
+    return None
+
+
+def main():
+    import copy
+    args = parse_args()
+    out = measure(args)
+    rank, _, world = setup(args)
+    if args.workload == "ground_bunny" and not args.no_soup and not args.emulate_split and args.spp == 1 and args.variant == 0:
+        # north_star's scaling curve is quoted on the synthetic soup: same resolution, same split, a short run
+        a2 = copy.copy(args)
+        a2.workload, a2.frames, a2.steps, a2.warmup, a2.lights = "soup", 2, 3, 1, 1
+        a2.no_cpu_baseline = a2.no_pmc = a2.no_parity = True
+        o2 = measure(a2)
+        if rank == 0:
+            out["soup"] = {k: o2[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step")}
+            out["soup"].update({"workload": o2["config"]["workload"], "ms_per_frame": o2["config"]["ms_per_frame"], "pipeline": o2["config"]["pipeline"],
+                                "kernels": o2["kernels"], "note": "secondary measurement for the N-GPU curve north_star quotes on the soup; `value` above stays the headline workload"})
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 
@@ -302,29 +370,167 @@ class soup_workload:
         self.recipe = None          # no reference replay for this workload in cpu_reference()
 
 
-def measured_traffic(workload, kernel, W, H, L):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written
-    by profiles/pmc_summary.py from FETCH_SIZE / WRITE_SIZE collected in separate passes), or None."""
+PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+
+
+def collect_pmc(argv, kernel):
+    """Counters of the dominant kernel, collected NOW: rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py <same workload>,
+    one child process per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace domain is combined with
+    --pmc).  Returns per-launch means, or None when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    keep, skip = [], False
+    for a in argv:                                  # the child renders the same workload, briefly
+        if skip:
+            skip = False; continue
+        if a in ("--steps", "--warmup", "--frames"):
+            skip = True; continue
+        if a.startswith(("--steps=", "--warmup=", "--frames=")) or a in ("--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"):
+            continue
+        keep.append(a)
+    child = ["python3", os.path.join(ROOT, "bench.py")] + keep + ["--steps", "2", "--warmup", "1", "--frames", "4", "--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"]
+    vals, durs = {}, []
+    tmp = tempfile.mkdtemp(prefix="srt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for i, grp in enumerate(PMC_GROUPS):
+            d = os.path.join(tmp, f"pass{i}")
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode:
+                print(f"bench: rocprofv3 pass {grp} failed (rc {r.returncode}); using profiles/traffic.json", file=sys.stderr)
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    nm = row["Kernel_Name"].replace("void ", "")
+                    if nm.startswith(kernel) and "<true" not in nm:          # not the counting build
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c, v in acc.items():
+                vals[c] = sum(v) / len(v)
+            if i == 0:
+                for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
+                    for row in csv.DictReader(open(f)):
+                        nm = row["Kernel_Name"].replace("void ", "")
+                        if nm.startswith(kernel) and "<true" not in nm:
+                            durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+    except Exception as e:          # profiling is evidence, not a requirement of the measurement
+        print(f"bench: PMC collection failed ({e}); using profiles/traffic.json", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    need = ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE")
+    if any(k not in vals for k in need):
+        return None
+    return {"source": f"rocprofv3 --pmc child passes of this run ({time.perf_counter() - t0:.0f} s, {len(durs)} launches)", "counters": vals,
+            "kernel_ms_under_profiler": sum(durs) / len(durs) if durs else None}
+
+
+def committed_pmc(workload, kernel, W, H, L):
+    """Fallback: the counters of the committed profiling passes (profiles/traffic.json), when this run cannot profile itself."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        t = json.load(f)
-    return t.get(f"{workload}_{W}x{H}_L{L}", {}).get(kernel)
+        t = json.load(f).get(f"{workload}_{W}x{H}_L{L}", {})
+    v = t.get("_valu", {}).get(kernel)
+    if kernel not in t or not v:
+        return None
+    return {"source": "profiles/traffic.json (committed rocprofv3 passes of an earlier run, NOT this run)",
+            "counters": {"SQ_INSTS_VALU": v["insts"], "GRBM_GUI_ACTIVE": v["cycles"] * 8, "SQ_THREAD_CYCLES_VALU": (v.get("lanes_active") or 0) * v["insts"]},
+            "traffic_bytes": t[kernel], "kernel_ms_under_profiler": None}
 
 
-def measured_valu(workload, kernel, W, H, L):
-    """VALU issue utilisation of `kernel` from the committed PMC passes: a wave64 VALU instruction holds its SIMD for 4
-    cycles, the chip has 256 CUs x 4 SIMDs.  None when this workload was not profiled."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        v = json.load(f).get(f"{workload}_{W}x{H}_L{L}", {}).get("_valu", {}).get(kernel)
-    if not v or not v.get("cycles"):
-        return None
-    return {"wave_insts_per_launch": v["insts"], "launch_cycles": v["cycles"], "lanes_active_of_64": v.get("lanes_active"),
-            "issue_frac": round(v["insts"] * 4 / (1024 * v["cycles"]), 4), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
+def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
+    """The bound is chosen from counters, not assumed.  HBM: (2 x FETCH_SIZE + WRITE_SIZE) per launch (KiB; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950 -- an upper bound for the narrower ones) over the launch time
+    against 8 TB/s.  VALU: a wave64 VALU instruction holds its SIMD for 4 cycles, so wave-instructions x 4 / (1024 SIMDs x launch
+    cycles) is the issue utilisation; times the active lanes per instruction / 64 it is the fraction of the lane-operation peak
+    (1024 SIMDs x 16 lanes x clock).  bound = "hbm" when the HBM fraction is at least 25 % and the larger of the two, else "valu".
+    The algorithmic-bytes rate of SURVEY.md s8(d) is kept as a labelled EFFECTIVE figure: records come from L2 / Infinity Cache."""
+    scene_mb = (g.flat.n_nodes * 32 + g.flat.n_tris * 96) / 1e6
+    eff = {"effective_algorithmic_GBps": round(effective_gbs, 2), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+           "effective_note": "32 B x slab tests + 36 B x triangle tests (+ per-pixel bytes) of the kernel's own traversal per launch time: NOT HBM traffic -- "
+                             f"the {scene_mb:.1f} MB of records are served by L2 / Infinity Cache, so this rate can exceed the HBM peak"}
+    if pmc is None or kernel_ms <= 0:
+        return {"bound": "unmeasured", "kernel": kernel, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "kernel_ms": round(kernel_ms, 5), **eff}
+    c = pmc["counters"]
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0                         # summed over the 8 XCDs
+    prof_ms = pmc.get("kernel_ms_under_profiler") or kernel_ms
+    clock_ghz = cycles / (prof_ms * 1e6)
+    insts = c["SQ_INSTS_VALU"]
+    lanes = (c.get("SQ_THREAD_CYCLES_VALU", 0.0) / insts) if insts else 0.0
+    issue = insts * 4.0 / (1024.0 * cycles) if cycles else 0.0
+    valu_frac = issue * lanes / 64.0
+    traffic = pmc.get("traffic_bytes")
+    if traffic is None:
+        traffic = 2 * 1024.0 * c["FETCH_SIZE"] + 1024.0 * c["WRITE_SIZE"]
+    hbm_gbs = traffic / (prof_ms * 1e-3) / 1e9
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS
+    common = {"kernel": kernel, "kernel_ms": round(kernel_ms, 5), "kernel_ms_under_profiler": round(prof_ms, 5), "traffic": int(traffic),
+              "hbm_GBps": round(hbm_gbs, 1), "hbm_frac": round(hbm_frac, 4),
+              "valu": {"wave_insts_per_launch": int(insts), "launch_cycles": int(cycles), "clock_GHz": round(clock_ghz, 3), "issue_frac": round(issue, 4),
+                       "lanes_active_of_64": round(lanes, 1), "frac_of_lane_peak": round(valu_frac, 4)},
+              "source": pmc["source"], **eff}
+    if hbm_frac >= 0.25 and hbm_frac >= valu_frac:
+        return {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), **common}
+    peak = 1024 * 16 * clock_ghz / 1e3                          # T lane-operations / s at the clock the launch ran at
+    return {"bound": "valu", "achieved": round(insts * lanes / (prof_ms * 1e-3) / 1e12, 3), "peak": round(peak, 3), "unit": "Tlaneop/s",
+            "frac": round(valu_frac, 4), **common}
+
+
+def parity_block(g, args, W, H, L, lights, hit, t, lin, rgb8):
+    """BASELINE.json's metric names both halves: the frame the timed region rendered last, against (i) the committed reference
+    golden of this workload at this size when there is one (hit ids and rgb8 in full, pre-tone-map floats on the stored
+    subsample), else (ii) the CPU oracle on a band of scanlines of the same frame."""
+    import golden_util as gu
+    out = {"tolerance_max_abs_dRGB_linear": 1e-4}
+    gold = g.out(W, H, L, "hit_id") if hasattr(g, "out") and args.spp == 1 else None
+    if gold is not None:
+        ref8 = g.out(W, H, L, "rgb8")
+        d8 = np.abs(rgb8.astype(np.int32) - ref8.astype(np.int32))
+        st = int(g.out(W, H, L, "sub_stride")) if g.out(W, H, L, "sub_stride") is not None else 1
+        ref_lin = g.out(W, H, L, "sub_lin") if st > 1 else g.out(W, H, L, "lin").reshape(-1, 3)
+        got_lin = lin.reshape(-1, 3)[::st]
+        out.update({"against": f"tests/golden/scene_{g.name}.npz (outputs of the compiled reference, {W}x{H}, {L} light sample(s))",
+                    "hit_id_mismatches": int((hit != gold).sum()), "t_bitwise_equal": gu.sha(t) == str(g.out(W, H, L, "sha_t")),
+                    "max_abs_dRGB_linear": float(np.abs(got_lin - ref_lin).max()), "linear_samples_compared": int(ref_lin.shape[0]),
+                    "rgb8_pixels_differing": int((d8.max(-1) > 0).sum()), "rgb8_max_LSB": int(d8.max()), "pixels": int(W * H)})
+        return out
+    bands = [b for b in getattr(g, "bands", []) if b[:3] == (W, H, L)] if args.spp == 1 else []
+    if bands:           # a band of scanlines of this very frame that the compiled reference rendered (K4: a whole frame is hours of reference time)
+        _, _, _, y0, y1 = bands[-1]
+        sl = slice(y0, y1)
+        ref8 = g.band_out(W, H, L, y0, y1, "rgb8")
+        d8 = np.abs(rgb8[sl].astype(np.int32) - ref8.astype(np.int32))
+        st = int(g.band_out(W, H, L, y0, y1, "sub_stride"))
+        out.update({"against": f"tests/golden/scene_{g.name}.npz (the compiled reference's render of scanlines {y0}..{y1 - 1} of this {W}x{H} frame, {L} light samples)",
+                    "hit_id_mismatches": int((hit[sl] != g.band_out(W, H, L, y0, y1, "hit_id")).sum()),
+                    "t_bitwise_equal": gu.sha(np.ascontiguousarray(t[sl])) == str(g.band_out(W, H, L, y0, y1, "sha_t")),
+                    "max_abs_dRGB_linear": float(np.abs(np.ascontiguousarray(lin[sl]).reshape(-1, 3)[::st] - g.band_out(W, H, L, y0, y1, "sub_lin")).max()),
+                    "rgb8_pixels_differing": int((d8.max(-1) > 0).sum()), "rgb8_max_LSB": int(d8.max()), "pixels": int(W * (y1 - y0))})
+        return out
+    from oracle import pyoracle as po
+    from simple_raytracer_amd import abi
+    band = 8
+    y0 = (H // 2) // band * band
+    p = abi.make_params(W, H, lights, block_rows=band, block_first=y0 // band, block_stride=10 ** 6, spp=args.spp)
+    c = po.render(g.flat, p)
+    sl = slice(y0, y0 + band)
+    d8 = np.abs(rgb8[sl].astype(np.int32) - c["rgb8"].astype(np.int32))
+    out.update({"against": f"CPU oracle (oracle/srt_oracle.c) on scanlines {y0}..{y0 + band - 1} of the same frame",
+                "hit_id_mismatches": int((hit[sl] != c["hit_id"]).sum()), "t_bitwise_equal": bool(np.array_equal(t[sl].view(np.uint32), c["t"].view(np.uint32))),
+                "max_abs_dRGB_linear": float(np.abs(lin[sl] - c["rgb_linear"]).max()), "rgb8_pixels_differing": int((d8.max(-1) > 0).sum()),
+                "rgb8_max_LSB": int(d8.max()), "pixels": int(W * band)})
+    return out
 
 
 def cpu_reference(g, W, H):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 1
+#define SRT_ABI_VERSION 2
 
 /* ---- error codes (the reference signals nothing: it prints, throws or crashes) -- */
 enum {
@@ -98,6 +98,13 @@ typedef struct srt_params {
      * block_first, block_first+block_stride, ...  Output row r_local = k*block_rows + (y % block_rows)
      * for the k-th owned block.  Whole frame on one device: block_rows = height, first 0, stride 1. */
     uint32_t block_rows, block_first, block_stride;
+    /* block_cols = 0: full-width scanline blocks, as above.  block_cols = C > 0 (C and block_rows multiples of 8): the frame is cut
+     * into tiles of block_rows x C pixels and tile (bx, by) belongs to the call with (bx + by) % block_stride == block_first -- a
+     * diagonal deal, so that every call owns tiles in every block row and every block column (expensive pixels cluster: tree crowns,
+     * a bunny; whole-width rows spread them over 8 devices only coarsely).  Output: `height` rows x srt_cols_owned(p) columns; local
+     * column xl of image row y is image column ((xl / C) * block_stride + (block_first + block_stride - (y / block_rows) %
+     * block_stride) % block_stride) * C + xl % C, and local columns whose image column is >= width are padding (not written). */
+    uint32_t block_cols;
     float    focal;                /* 400 (:506)                                                    */
     uint32_t n_lights;             /* lightAmount (:348,445)                                        */
     const float* light_pos;        /* n_lights x 3, host-accumulated staircase (:372-382)           */
@@ -143,8 +150,9 @@ void srt_params_default(srt_params* p, uint32_t width, uint32_t height);
  * x, y, z, x, ... += 3.0f accumulated in f32 exactly as the reference does.  out = n x 3. */
 void srt_light_staircase(const float base[3], uint32_t n, float* out);
 
-/* Number of rows a call with these params writes (<= height). */
+/* Number of rows a call with these params writes (<= height) and the width of those rows (width unless block_cols > 0). */
 uint32_t srt_rows_owned(const srt_params* p);
+uint32_t srt_cols_owned(const srt_params* p);
 
 /* Validate + upload a flat scene to HIP device `device`.  The descriptor's arrays are only read
  * during the call. */
@@ -173,6 +181,14 @@ int srt_sync(srt_scene* s, srt_stats* stats);
 /* Device-resident size of the scene records and the per-record algorithmic byte sizes used by
  * the bytes model: 32 B per node test, 36 B per triangle test. */
 uint64_t srt_scene_device_bytes(const srt_scene* s);
+
+/* Which kernels the last srt_render* on this scene launched, in order, e.g. "k_trace_nq+k_shade_tile" (DESIGN.md s5 explains
+ * how the pipeline is chosen per scene and light-sample count).  The string lives as long as the scene. */
+const char* srt_scene_pipeline(const srt_scene* s);
+
+/* Expected slab tests per ray from the surface areas of the scene's node boxes (what decides whether primary rays take the
+ * packet walk: hierarchies of heavily overlapping boxes do). */
+double srt_scene_overlap_estimate(const srt_scene* s);
 
 /* ---- known-answer entry points: the DEVICE leaf functions on caller vectors (host pointers), so that the
  * reference's known-answer fixtures pin the device code directly.  Layouts as in tests/golden/kat.npz:

@@ -44,6 +44,8 @@ def oracle_lib():
                                     C.POINTER(abi.Stats), C.c_int]
         L.oracle_rows_owned.restype = C.c_uint32
         L.oracle_rows_owned.argtypes = [C.POINTER(abi.Params)]
+        L.oracle_cols_owned.restype = C.c_uint32
+        L.oracle_cols_owned.argtypes = [C.POINTER(abi.Params)]
         L.oracle_num_threads.restype = C.c_int
         _oracle = L
     return _oracle
@@ -57,10 +59,10 @@ def render(scene: abi.FlatScene, params: abi.Params, n_threads=0):
     """Run the C restatement.  Returns dict(hit_id, t, rgb_linear, rgb_tone, rgb8, stats)."""
     L = oracle_lib()
     rows = L.oracle_rows_owned(C.byref(params))
-    W = params.width
-    out = dict(hit_id=np.empty((rows, W), np.int32), t=np.empty((rows, W), np.float32),
-               rgb_linear=np.empty((rows, W, 3), np.float32), rgb_tone=np.empty((rows, W, 3), np.float32),
-               rgb8=np.empty((rows, W, 3), np.uint8))
+    W = L.oracle_cols_owned(C.byref(params))           # width of the rows this call writes (padding of a tile deal stays zero)
+    out = dict(hit_id=np.zeros((rows, W), np.int32), t=np.zeros((rows, W), np.float32),
+               rgb_linear=np.zeros((rows, W, 3), np.float32), rgb_tone=np.zeros((rows, W, 3), np.float32),
+               rgb8=np.zeros((rows, W, 3), np.uint8))
     st = abi.Stats()
     d = scene.desc()
     rc = L.oracle_render(C.byref(d), C.byref(params), _p(out["hit_id"], _i32p), _p(out["t"], _f32p),

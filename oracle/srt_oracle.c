@@ -157,8 +157,22 @@ void oracle_light_staircase(const float base[3], uint32_t n, float* out) {
     }
 }
 
+/* include/srt.h srt_params.block_cols: tiles of block_rows x block_cols pixels, tile (bx, by) owned iff (bx + by) % stride == first */
+uint32_t oracle_cols_owned(const srt_params* p) {
+    if (!p->block_stride) return 0;
+    if (!p->block_cols) return p->width;
+    uint32_t n_bx = (p->width + p->block_cols - 1) / p->block_cols;
+    return (n_bx + p->block_stride - 1) / p->block_stride * p->block_cols;
+}
+static uint32_t image_col(const srt_params* p, uint32_t xl, uint32_t y) {
+    if (!p->block_cols) return xl;
+    uint32_t off = (p->block_first + p->block_stride - (y / p->block_rows) % p->block_stride) % p->block_stride;
+    return ((xl / p->block_cols) * p->block_stride + off) * p->block_cols + xl % p->block_cols;
+}
+
 uint32_t oracle_rows_owned(const srt_params* p) {
     if (!p->block_rows || !p->block_stride) return 0;
+    if (p->block_cols) return p->block_first < p->block_stride ? p->height : 0;
     uint32_t nblocks = (p->height + p->block_rows - 1) / p->block_rows, rows = 0;
     for (uint32_t b = p->block_first; b < nblocks; b += p->block_stride) {
         uint32_t y0 = b * p->block_rows, y1 = y0 + p->block_rows;
@@ -254,26 +268,31 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
         s.normal[i] = face_normal(d->tri_points + 12 * (size_t)i);
     }
     const uint32_t W = p->width, H = p->height;
-    const uint32_t rows = oracle_rows_owned(p);
+    const uint32_t rows = oracle_rows_owned(p), WL = oracle_cols_owned(p);      /* WL: width of the rows this call writes */
     /* row table: local row -> image y */
     uint32_t* row_y = (uint32_t*)malloc(sizeof(uint32_t) * (rows ? rows : 1));
-    {
+    if (p->block_cols) { for (uint32_t r = 0; r < rows; r++) row_y[r] = r; }
+    else {
         uint32_t nblocks = (H + p->block_rows - 1) / p->block_rows, r = 0;
         for (uint32_t b = p->block_first; b < nblocks; b += p->block_stride)
             for (uint32_t y = b * p->block_rows; y < (b + 1) * p->block_rows && y < H; y++) row_y[r++] = y;
     }
+    uint64_t n_pixels = 0;
     uint64_t hits = 0, node_tests = 0, tri_tests = 0, snode_tests = 0, stri_tests = 0;
     /* sendRaysAndIntersectPointsColors:511-517: i = px + int(-W/2), dir = (i, j, focal), origin 0 */
     const int i0 = (int)(-(float)W / 2), j0 = (int)(-(float)H / 2);
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, node_tests, tri_tests, snode_tests, stri_tests)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, node_tests, tri_tests, snode_tests, stri_tests, n_pixels)
 #endif
     for (uint32_t r = 0; r < rows; r++) {
         const uint32_t y = row_y[r];
         work_ctr w = { 0, 0 }, ws = { 0, 0 };
-        for (uint32_t x = 0; x < W; x++) {
-            const size_t pix = (size_t)r * W + x;
+        for (uint32_t xl = 0; xl < WL; xl++) {
+            const uint32_t x = image_col(p, xl, y);                 /* local column -> image column */
+            if (x >= W) continue;                                    /* padding of a tile deal: not written */
+            n_pixels++;
+            const size_t pix = (size_t)r * WL + xl;
             v3 o = v3make(0.0f, 0.0f, 0.0f);
             v3 sum = v3make(0.f, 0.f, 0.f), tone = v3make(0.f, 0.f, 0.f);
             int32_t q[3] = { 0, 0, 0 };
@@ -342,7 +361,7 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->primary_rays = (uint64_t)W * rows * spp;
+        stats->primary_rays = n_pixels * spp;
         stats->hit_rays = hits;
         stats->shadow_rays = hits * p->n_lights;
         stats->node_tests_primary = node_tests;

@@ -38,7 +38,7 @@ class SceneDesc(C.Structure):
 class Params(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32),
-        ("block_rows", C.c_uint32), ("block_first", C.c_uint32), ("block_stride", C.c_uint32),
+        ("block_rows", C.c_uint32), ("block_first", C.c_uint32), ("block_stride", C.c_uint32), ("block_cols", C.c_uint32),
         ("focal", C.c_float),
         ("n_lights", C.c_uint32), ("light_pos", _f32p),
         ("shadow_div", C.c_float), ("reinhard", C.c_float), ("gamma", C.c_float),
@@ -167,7 +167,7 @@ def light_staircase(base, n):
     return out
 
 
-def make_params(width, height, lights, *, block_rows=None, block_first=0, block_stride=1,
+def make_params(width, height, lights, *, block_rows=None, block_first=0, block_stride=1, block_cols=0,
                 focal=400.0, shadow_div=5.0, reinhard=0.5, gamma=1.1, background=REFERENCE_BACKGROUND,
                 spp=1, flags=0):
     """srt_params with the reference's literals; `lights` is an (n,3) f32 array kept alive on the
@@ -175,7 +175,7 @@ def make_params(width, height, lights, *, block_rows=None, block_first=0, block_
     p = Params()
     p.width, p.height = int(width), int(height)
     p.block_rows = int(block_rows if block_rows else height)
-    p.block_first, p.block_stride = int(block_first), int(block_stride)
+    p.block_first, p.block_stride, p.block_cols = int(block_first), int(block_stride), int(block_cols)
     p.focal = focal
     lights = np.ascontiguousarray(np.asarray(lights, np.float32).reshape(-1, 3))
     p.n_lights = lights.shape[0]
@@ -185,6 +185,21 @@ def make_params(width, height, lights, *, block_rows=None, block_first=0, block_
     p.background[0], p.background[1], p.background[2], p.background[3] = background[0], background[1], background[2], 0
     p.spp, p.flags = spp, flags
     return p
+
+
+def owned_pixels(width, height, block_rows, block_first, block_stride, block_cols=0):
+    """Image pixel (flat index y * width + x) of every local output pixel of a call with these block params, as an int64 array
+    [rows_local, cols_local]; -1 = padding.  Mirrors include/srt.h (srt_params.block_rows / block_cols)."""
+    if not block_cols:
+        ys = rows_owned(height, block_rows, block_first, block_stride)
+        return ys[:, None] * width + np.arange(width, dtype=np.int64)[None, :]
+    n_bx = (width + block_cols - 1) // block_cols
+    wl = (n_bx + block_stride - 1) // block_stride * block_cols
+    y = np.arange(height, dtype=np.int64)[:, None]
+    xl = np.arange(wl, dtype=np.int64)[None, :]
+    off = (block_first + block_stride - (y // block_rows) % block_stride) % block_stride
+    x = ((xl // block_cols) * block_stride + off) * block_cols + xl % block_cols
+    return np.where(x < width, y * width + x, -1)
 
 
 def rows_owned(height, block_rows, block_first, block_stride):

@@ -65,6 +65,7 @@ struct srt_scene {
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
+    char pipeline[96] = "";                       // kernels of the last render, in launch order
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
     uint32_t* ws_qlist = nullptr; uint32_t* d_qcount = nullptr; uint32_t qcap = 0;      // quadrants with hits: 64 shard lists of qcap entries, their counters
     double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
@@ -142,7 +143,7 @@ const char* srt_strerror(int code) {
 void srt_params_default(srt_params* p, uint32_t width, uint32_t height) {
     std::memset(p, 0, sizeof(*p));
     p->width = width; p->height = height;
-    p->block_rows = height; p->block_first = 0; p->block_stride = 1;
+    p->block_rows = height; p->block_first = 0; p->block_stride = 1; p->block_cols = 0;
     p->focal = 400.0f;                 // simple_raytracer.cpp:506
     p->n_lights = 1;                   // :445
     p->light_pos = nullptr;
@@ -161,8 +162,31 @@ void srt_light_staircase(const float base[3], uint32_t n, float* out) {
     }
 }
 
+uint32_t srt_cols_owned(const srt_params* p) {
+    if (!p || !p->block_stride) return 0;
+    if (!p->block_cols) return p->width;
+    const uint32_t n_bx = (p->width + p->block_cols - 1) / p->block_cols;
+    return (n_bx + p->block_stride - 1) / p->block_stride * p->block_cols;      // padded: every block row has the same local width
+}
+
+// pixels of the image a call with these params renders (padding of a tile deal excluded)
+static uint64_t pixels_owned(const srt_params* p) {
+    if (!p->block_cols) return (uint64_t)p->width * srt_rows_owned(p);
+    const uint32_t n_bx = (p->width + p->block_cols - 1) / p->block_cols, n_by = (p->height + p->block_rows - 1) / p->block_rows;
+    uint64_t n = 0;
+    for (uint32_t by = 0; by < n_by; by++) {
+        const uint32_t h = (by + 1) * p->block_rows <= p->height ? p->block_rows : p->height - by * p->block_rows;
+        for (uint32_t bx = (p->block_first + p->block_stride - by % p->block_stride) % p->block_stride; bx < n_bx; bx += p->block_stride) {
+            const uint32_t w = (bx + 1) * p->block_cols <= p->width ? p->block_cols : p->width - bx * p->block_cols;
+            n += (uint64_t)w * h;
+        }
+    }
+    return n;
+}
+
 uint32_t srt_rows_owned(const srt_params* p) {
     if (!p || !p->block_rows || !p->block_stride) return 0;
+    if (p->block_cols) return p->block_first < p->block_stride ? p->height : 0;      // tiles dealt in two dimensions: tiles in every row
     const uint32_t nblocks = (p->height + p->block_rows - 1) / p->block_rows;
     uint32_t rows = 0;
     for (uint32_t b = p->block_first; b < nblocks; b += p->block_stride) {
@@ -394,12 +418,15 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
 void srt_debug_fail_host_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
+const char* srt_scene_pipeline(const srt_scene* s) { return s ? s->pipeline : ""; }
+double srt_scene_overlap_estimate(const srt_scene* s) { return s ? s->overlap : 0.; }
 
 static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) & 0xffu; }
 
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
+    if (p->block_cols && ((p->block_cols & 7u) || (p->block_rows & 7u) || p->block_first >= p->block_stride)) return SRT_ERR_ARG;   // tiles of whole 8x8 pixel blocks
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
     { const uint32_t n = (uint32_t)std::lround(std::sqrt((double)p->spp)); if (n * n != p->spp) return SRT_ERR_ARG; }   // n x n sub-pixel grid
     if ((uint64_t)p->width * p->height >= (1ull << 31)) return SRT_ERR_LIMIT;
@@ -417,14 +444,15 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t rows = srt_rows_owned(p);
+    const uint32_t wl = srt_cols_owned(p);    // width of the rows this call writes
     if (!rows) {                              // nothing to launch; work of an earlier render stays pending
         if (!s->pending) std::memset(&s->last, 0, sizeof(s->last));
         return SRT_OK;
     }
     std::memset(&s->last, 0, sizeof(s->last));
     s->last.rows = rows;
-    s->last.primary_rays = (uint64_t)p->width * rows;
-    const size_t pixels = (size_t)p->width * rows;
+    s->last.primary_rays = pixels_owned(p);
+    const size_t pixels = (size_t)wl * rows;
     // workspace for hit ids / t when the caller does not want them (the shade kernel does)
     if ((!d_hit_id || !d_t) && s->ws_pixels < pixels) {
         HIP_TRY(wait_idle(s));
@@ -470,7 +498,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
     dp.shadow_px_major = 0u;
     dp.xcd_rows = (s->bytes > (32ull << 20) || variant_of(p) == 18) ? 1u : 0u;       // records far beyond one XCD's 4 MiB L2 (variant 18: forced, for the tests)
-    dp.W = p->width; dp.H = p->height; dp.rows = rows;
+    dp.W = wl; dp.Wimg = p->width; dp.col_block = p->block_cols; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
     dp.i0 = (int)(-(float)p->width / 2); dp.j0 = (int)(-(float)p->height / 2);       // :511,513
     dp.sub_x = 0.0f; dp.sub_y = 0.0f;                                                 // rayXY = (0, 0), :507,514-515
@@ -478,8 +506,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     dp.shadow_div = p->shadow_div; dp.reinhard = p->reinhard; dp.gamma = p->gamma;
     dp.bg = (uint32_t)p->background[0] | ((uint32_t)p->background[1] << 8) | ((uint32_t)p->background[2] << 16);
 
-    const dim3 block(256), grid((p->width + 15) / 16, (rows + 15) / 16);
-    const dim3 grid8((p->width + 7) / 8, (rows + 7) / 8);          // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
+    const dim3 block(256), grid((wl + 15) / 16, (rows + 15) / 16);
+    const dim3 grid8((wl + 7) / 8, (rows + 7) / 8);                // 8x8 pixels per workgroup: 4 waves x (4x4 pixels)
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
@@ -531,11 +559,12 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             if (count) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next);
             else       hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next);
             HIP_TRY(hipGetLastError());
+            std::snprintf(s->pipeline, sizeof(s->pipeline), "k_closest_hit+k_shade");
             return SRT_OK;
         }
         // closest-hit kernel: CAP = node queue entries, TWL/THL = log2 tile size per wave, FILTER = filtered slab test
         #define LAUNCH_NQ(CAP, TWL, THL, FILTER) do { \
-            const dim3 g_((p->width + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
+            const dim3 g_((wl + (2u << TWL) - 1) / (2u << TWL), (rows + (2u << THL) - 1) / (2u << THL)); \
             if (count) hipLaunchKernelGGL((k_closest_hit_nq<true, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap); \
             else       hipLaunchKernelGGL((k_closest_hit_nq<false, CAP, TWL, THL, FILTER>), g_, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap); } while (0)
         // Pipelines (variant 0 picks per scene and light count; the numbered variants force one):
@@ -604,6 +633,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             HIP_TRY(hipGetLastError());
         }
         if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
+        std::snprintf(s->pipeline, sizeof(s->pipeline), "%s%s+k_shade_tile", fused ? "k_trace_nq" : (pk_closest ? "k_closest_hit_pk" : "k_closest_hit_nq"),
+                      fused || !p->n_lights ? "" : (pk_shadow ? "+k_shadow_pk" : "+k_shadow_nq"));
         DevParams sp = fp;
         sp.shadow_px_major = pk_shadow ? 1u : 0u;
         hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
@@ -650,7 +681,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     s->ctr_dirty = false;
     s->last_stream = stream;
     s->pending = true;
-    s->last.primary_rays = (uint64_t)p->width * rows * spp;
+    s->last.primary_rays = pixels_owned(p) * spp;
     s->last.shadow_rays = p->n_lights;     // multiplied by hit count in srt_sync
     return SRT_OK;
 }
@@ -706,7 +737,7 @@ int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, flo
     if (rc != SRT_OK) return rc;
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t rows = srt_rows_owned(p);
-    const size_t pixels = (size_t)p->width * rows;
+    const size_t pixels = (size_t)srt_cols_owned(p) * rows;
     if (pixels > s->ws_out_pixels) {
         HIP_TRY(wait_idle(s));
         if (s->ws_lin) (void)hipFree(s->ws_lin);

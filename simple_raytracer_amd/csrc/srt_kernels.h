@@ -31,7 +31,9 @@ struct DevScene {
 };
 
 struct DevParams {
-    uint32_t W, H, rows;
+    uint32_t W, H, rows;          // W = width of the rows this call writes (local width); rows of them
+    uint32_t Wimg;                // image width (== W unless the frame is dealt in tiles: col_block > 0)
+    uint32_t col_block;           // srt_params.block_cols: 0 = full-width scanline blocks
     uint32_t block_rows, block_first, block_stride;
     int32_t i0, j0;
     float sub_x, sub_y;           // sub-pixel offset added to dir.xy (0 for the reference's one ray per pixel)
@@ -70,6 +72,27 @@ __device__ __forceinline__ void zero_next_counters(unsigned long long* next) {
         for (int i = threadIdx.x; i < NCTR; i += 256) next[i] = 0ull;
 }
 
+// local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
+__device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
+    if (p.col_block) return r;                                             // tiles dealt in two dimensions: every call owns tiles in every row
+    if (p.block_stride == 1) return p.block_first * p.block_rows + r;      // consecutive blocks (whole frame on one device): no division
+    return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
+}
+// local output column -> image column (include/srt.h srt_params.block_cols); y = image row
+__device__ __forceinline__ uint32_t image_col(const DevParams& p, uint32_t px, uint32_t y) {
+    if (!p.col_block) return px;
+    const uint32_t off = (p.block_first + p.block_stride - (y / p.block_rows) % p.block_stride) % p.block_stride;     // owned bx = first - by (mod stride)
+    return ((px / p.col_block) * p.block_stride + off) * p.col_block + px % p.col_block;
+}
+// is local pixel (px, r) a pixel of the image (not beyond the buffer, not padding of a tile deal)?
+__device__ __forceinline__ bool pixel_live(const DevParams& p, uint32_t px, uint32_t r) {
+    return px < p.W && r < p.rows && (!p.col_block || image_col(p, px, r) < p.Wimg);
+}
+// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = x + int(-W/2); px = LOCAL column, y = image row
+__device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
+    return mk((float)(p.i0 + (int)image_col(p, px, y)) + p.sub_x, (float)(p.j0 + (int)y) + p.sub_y, p.focal);
+}
+
 // 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
 // a wave are neighbours, so they walk the same top-of-tree nodes (loads of one node by many lanes
 // coalesce into one 32 B fetch) and diverge only deep in the tree.
@@ -77,18 +100,8 @@ __device__ __forceinline__ bool tile_pixel(const DevParams& p, uint32_t& px, uin
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     r  = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    return px < p.W && r < p.rows;
+    return pixel_live(p, px, r);
 }
-// local output row -> image row under block-cyclic scanline ownership (include/srt.h srt_params)
-__device__ __forceinline__ uint32_t image_row(const DevParams& p, uint32_t r) {
-    if (p.block_stride == 1) return p.block_first * p.block_rows + r;      // consecutive blocks (whole frame on one device): no division
-    return ((r / p.block_rows) * p.block_stride + p.block_first) * p.block_rows + (r % p.block_rows);
-}
-// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = px + int(-W/2)
-__device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
-    return mk((float)(p.i0 + (int)px) + p.sub_x, (float)(p.j0 + (int)y) + p.sub_y, p.focal);
-}
-
 // =================================================================================================
 // Kernel 1: closest hit.  rayIntersection:405-431 with boundingBoxIntersection:296-317 fused in:
 // walk ALL slab-passing nodes of ALL objects in pre-order (== reference visit order), test leaf
@@ -328,7 +341,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
     const uint32_t tile_x = (bx * 2 + (wave & 1)) << TWL, tile_r = (by * 2 + (wave >> 1)) << THL;
     const uint32_t px = tile_x + (lane & ((1u << TWL) - 1)), r = tile_r + ((lane >> TWL) & ((1u << THL) - 1));
-    const bool live = lane < P && px < p.W && r < p.rows;
+    const bool live = lane < P && pixel_live(p, px, r);
     const V3 o = mk(0.0f, 0.0f, 0.0f);
     V3 dmine = mk(0.f, 0.f, p.focal);
     if (lane < P) {
@@ -569,7 +582,7 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
     if ((threadIdx.x >> 6) == 0) {
         const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
         const uint32_t px = bx * 8 + (quad & 1) * 4 + (ql & 3), r = by * 8 + (quad >> 1) * 4 + (ql >> 2);
-        const bool live = px < p.W && r < p.rows;
+        const bool live = pixel_live(p, px, r);
         const V3 o = mk(0.f, 0.f, 0.f);
         const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
         const RayRcp rc = ray_rcp(dd);
@@ -774,7 +787,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
     const uint32_t qx = wave & 1, qy = wave >> 1;
     const uint32_t tile_x = bx * 8 + qx * 4, tile_r = by * 8 + qy * 4;
     const uint32_t px = tile_x + (lane & 3), r = tile_r + ((lane >> 2) & 3);
-    const bool live = lane < NQ_P && px < p.W && r < p.rows;
+    const bool live = lane < NQ_P && pixel_live(p, px, r);
     const size_t tile_index = (size_t)by * gx + bx;
     unsigned long long n_node = 0, n_tri = 0;
     if (!live) id = -1;
@@ -970,7 +983,7 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
     const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
-    if (lane < NQ_P && px < p.W && r < p.rows) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
+    if (lane < NQ_P && pixel_live(p, px, r)) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
     const uint32_t l_begin = l_chunk == 0xffffffffu ? 0u : blockIdx.z * l_chunk;
     shadow_phase<SEQ, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave,
                                          l_begin, l_chunk == 0xffffffffu ? 0xffffffffu : l_begin + l_chunk);

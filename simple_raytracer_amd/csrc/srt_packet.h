@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
     const uint32_t lane = threadIdx.x & 63;
     uint32_t px, r;
     tile_lane_pixel(bx, by, lane, px, r);
-    const bool live = px < p.W && r < p.rows;
+    const bool live = pixel_live(p, px, r);
     const V3 d = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
     unsigned long long n_node = 0, n_tri = 0;
     float best; int32_t id;

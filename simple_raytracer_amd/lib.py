@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 
 # every symbol include/srt.h declares
-ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_scene_create", "srt_scene_destroy",
+ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy",
                "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
                "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
-               "srt_debug_fail_host_allocs")
+               "srt_debug_fail_host_allocs", "srt_scene_pipeline", "srt_scene_overlap_estimate")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -47,6 +47,8 @@ def load():
         L.srt_light_staircase.restype = None
         L.srt_rows_owned.argtypes = [C.POINTER(abi.Params)]
         L.srt_rows_owned.restype = C.c_uint32
+        L.srt_cols_owned.argtypes = [C.POINTER(abi.Params)]
+        L.srt_cols_owned.restype = C.c_uint32
         L.srt_scene_create.argtypes = [C.c_int, C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
         L.srt_scene_create.restype = C.c_int
         L.srt_scene_destroy.argtypes = [C.c_void_p]
@@ -59,6 +61,10 @@ def load():
         L.srt_sync.restype = C.c_int
         L.srt_scene_device_bytes.argtypes = [C.c_void_p]
         L.srt_scene_device_bytes.restype = C.c_uint64
+        L.srt_scene_pipeline.argtypes = [C.c_void_p]
+        L.srt_scene_pipeline.restype = C.c_char_p
+        L.srt_scene_overlap_estimate.argtypes = [C.c_void_p]
+        L.srt_scene_overlap_estimate.restype = C.c_double
         L.srt_strerror.argtypes = [C.c_int]
         L.srt_strerror.restype = C.c_char_p
         L.srt_last_hip_error.restype = C.c_int
@@ -107,12 +113,25 @@ class DeviceScene:
     def device_bytes(self):
         return int(self.L.srt_scene_device_bytes(self.h))
 
+    @property
+    def pipeline(self):
+        """Kernels of the last render, in launch order."""
+        return self.L.srt_scene_pipeline(self.h).decode()
+
+    @property
+    def overlap_estimate(self):
+        return float(self.L.srt_scene_overlap_estimate(self.h))
+
     def rows(self, params):
         return int(self.L.srt_rows_owned(C.byref(params)))
 
+    def cols(self, params):
+        """Width of the rows a call with these params writes (params.width unless the frame is dealt in tiles)."""
+        return int(self.L.srt_cols_owned(C.byref(params)))
+
     def render(self, params: abi.Params, want=("hit_id", "t", "rgb_linear", "rgb8")):
         """srt_render: host buffers out.  Returns dict of numpy arrays + 'stats'."""
-        rows, W = self.rows(params), params.width
+        rows, W = self.rows(params), self.cols(params)
         out = {}
         if "hit_id" in want: out["hit_id"] = np.empty((rows, W), np.int32)
         if "t" in want: out["t"] = np.empty((rows, W), np.float32)

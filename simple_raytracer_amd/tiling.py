@@ -1,10 +1,12 @@
-"""Multi-GPU image tiling for the ray-trace path: block-cyclic scanline ownership + one gather.
+"""Multi-GPU image tiling for the ray-trace path: block-cyclic ownership of scanline blocks (or of tiles) + one gather.
 
 Pixels are independent (sendRaysAndIntersectPointsColors, simple_raytracer.cpp:511-517) and the scene
 is read-only, so the frame shards with no data-path exchange except the final assembly of the
 framebuffer on rank 0.  Scanline block b (BLOCK_ROWS rows) belongs to rank b mod world: sky rows and
 object rows are dealt round-robin, which keeps the ranks' work balanced where contiguous bands
-would not be.  One process per GPU; the collective is torch.distributed (backend "nccl" = RCCL over
+would not be.  With block_cols > 0 the blocks are cut into tiles of BLOCK_ROWS x block_cols pixels and tile (bx, by) belongs
+to rank (bx + by) mod world (include/srt.h srt_params.block_cols): expensive pixels cluster in both directions (a tree crown, a
+bunny), and whole-width rows spread a cluster over 8 ranks only coarsely.  One process per GPU; the collective is torch.distributed (backend "nccl" = RCCL over
 xGMI on the GPUs, "gloo" in the CPU tests).  torch is plumbing here: device memory and the collective.
 """
 from __future__ import annotations
@@ -33,7 +35,7 @@ class FrameGather:
     """
 
     def __init__(self, width, height, block_rows, rank, world, device, channels=3, dtype=torch.uint8, dst=0, frames=1,
-                 stage_through_host=False, slots=1, frame_groups=1):
+                 stage_through_host=False, slots=1, frame_groups=1, block_cols=0):
         """frame_groups = F: the `frames` of a step are dealt to F groups of R = world / F ranks (frame f belongs to group
         f % F); inside a group every frame is split into scanline blocks over the group's R ranks.  Rank r is member
         r % R of group r // R.  F = 1 is the pure scanline split, F = world whole frames per rank."""
@@ -41,25 +43,33 @@ class FrameGather:
         self.W, self.H, self.block_rows, self.rank, self.world, self.dst = width, height, block_rows, rank, world, dst
         self.groups, self.per_group = frame_groups, world // frame_groups
         self.group, self.member = rank // self.per_group, rank % self.per_group
-        self.rows_of = [abi.rows_owned(height, block_rows, r % self.per_group, self.per_group) for r in range(world)]
-        self.rows = len(self.rows_of[rank])
-        self.max_rows = max(len(r) for r in self.rows_of)
+        self.block_cols = block_cols if self.per_group > 1 else 0
+        # per rank: image pixel (flat index) of every local output pixel, -1 = padding of a tile deal
+        self.pix_of = [abi.owned_pixels(width, height, block_rows, r % self.per_group, self.per_group, self.block_cols) for r in range(world)]
+        self.rows, self.cols = self.pix_of[rank].shape
+        self.max_rows = max(p.shape[0] for p in self.pix_of)
+        self.max_cols = max(p.shape[1] for p in self.pix_of)
         self.frames_total = frames
         frames = frames // frame_groups              # frames this rank renders per step
         self.frames = frames
         self.stage = stage_through_host            # gloo rehearsal on a GPU box: collectives on host copies
         # [frames, rows, W, C]: a step's frames travel in ONE collective (few, large messages suit the
         # point-to-point xGMI links: 7 peers -> rank 0, each over its own link)
-        self.tiles = [torch.zeros((frames, self.max_rows, width, channels), dtype=dtype, device=device) for _ in range(slots)]
+        self.tiles = [torch.zeros((frames, self.max_rows, self.max_cols, channels), dtype=dtype, device=device) for _ in range(slots)]
         self.tile = self.tiles[0]
         self.work = [None] * slots
         self._host = [None] * slots
         if rank == dst:
             self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(slots)] if world > 1 else None
             self.frame = torch.empty((self.frames_total, height, width, channels), dtype=dtype, device=device)
-            self.index = [torch.as_tensor(np.asarray(r), dtype=torch.long, device=device) for r in self.rows_of]
+            # sender r: positions of its real pixels inside the padded [max_rows, max_cols] tile, and where they go in the frame
+            self.src, self.index = [], []
+            for pm in self.pix_of:
+                pos = (np.arange(pm.shape[0], dtype=np.int64)[:, None] * self.max_cols + np.arange(pm.shape[1], dtype=np.int64)[None, :])[pm >= 0]
+                self.src.append(torch.as_tensor(pos, dtype=torch.long, device=device))
+                self.index.append(torch.as_tensor(pm[pm >= 0], dtype=torch.long, device=device))
         else:
-            self.recv, self.frame, self.index = None, None, None
+            self.recv, self.frame, self.index, self.src = None, None, None, None
 
     def start(self, k=0):
         """Begin the gather of slot k (asynchronous on the collective's stream)."""
@@ -77,7 +87,7 @@ class FrameGather:
         """Wait (stream-wise) for slot k's gather and de-interleave it into `frame` on rank dst.  Returns `frame`
         [frames, H, W, C] on dst (None elsewhere, or if slot k has no gather in flight)."""
         if self.world == 1:
-            return self.tiles[k][:, : self.rows]
+            return self.tiles[k][:, : self.rows, : self.cols]
         if self.work[k] is None:
             return None
         self.work[k].wait()
@@ -88,10 +98,12 @@ class FrameGather:
             _, recv = self._host[k]
             for r in range(self.world):
                 self.recv[k][r].copy_(recv[r])
+        C = self.frame.shape[-1]
         for r in range(self.world):
-            n = len(self.rows_of[r])
-            if n:       # sender r holds rows rows_of[r] of the frames of its group: frames group, group + F, ...
-                self.frame[r // self.per_group :: self.groups].index_copy_(1, self.index[r], self.recv[k][r][:, :n])
+            if self.index[r].numel():       # sender r holds its pixels of the frames of its group: frames group, group + F, ...
+                mine = self.frame[r // self.per_group :: self.groups]
+                flat = self.recv[k][r].reshape(mine.shape[0], -1, C).index_select(1, self.src[r])
+                mine.view(mine.shape[0], -1, C).index_copy_(1, self.index[r], flat)
         return self.frame
 
     def finish_all(self):
@@ -107,8 +119,8 @@ class FrameGather:
         return self.finish(k)
 
 
-def split_params(width, height, lights, rank, world, block_rows, **kw):
-    """srt_params of rank `rank` for a frame tiled over `world` ranks."""
+def split_params(width, height, lights, rank, world, block_rows, block_cols=0, **kw):
+    """srt_params of rank `rank` for a frame tiled over `world` ranks (block_cols > 0: tiles dealt in two dimensions)."""
     if world == 1:
         return abi.make_params(width, height, lights, **kw)
-    return abi.make_params(width, height, lights, block_rows=block_rows, block_first=rank, block_stride=world, **kw)
+    return abi.make_params(width, height, lights, block_rows=block_rows, block_first=rank, block_stride=world, block_cols=block_cols, **kw)

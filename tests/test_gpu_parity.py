@@ -119,6 +119,30 @@ def test_scanline_blocks_reassemble_bitwise(srt):
         assert np.array_equal(bits(lin), bits(whole["rgb_linear"])) and np.array_equal(bits(t), bits(whole["t"]))
 
 
+@pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("main_nocats", 150, 100, 9), ("cubes4_a0", 128, 96, 3)])
+def test_tiles_dealt_in_two_dimensions_reassemble_bitwise(srt, name, W, H, L):
+    """srt_params.block_cols: tiles of block_rows x block_cols pixels, tile (bx, by) owned by (bx + by) % stride.  Every split
+    reassembles to the whole frame bit for bit (incl. widths that are not a multiple of the tile and the padded local columns),
+    with every pipeline that serves these light counts (fused, packet shadow kernel from the quadrant list)."""
+    g, ds = device_scene(srt, name)
+    whole = ds.render(g.params(W, H, L))
+    for world, rows, cols in [(2, 8, 64), (8, 8, 8), (3, 16, 24), (5, 8, 16)]:
+        hit = np.full(H * W, -9, np.int32); rgb8 = np.zeros((H * W, 3), np.uint8)
+        lin = np.zeros((H * W, 3), np.float32); t = np.zeros(H * W, np.float32)
+        n_px = 0
+        for rank in range(world):
+            o = ds.render(g.params(W, H, L, block_rows=rows, block_first=rank, block_stride=world, block_cols=cols))
+            idx = abi.owned_pixels(W, H, rows, rank, world, cols)
+            assert o["hit_id"].shape == idx.shape
+            m = idx >= 0
+            hit[idx[m]] = o["hit_id"][m]; rgb8[idx[m]] = o["rgb8"][m]; lin[idx[m]] = o["rgb_linear"][m]; t[idx[m]] = o["t"][m]
+            n_px += int(m.sum())
+            assert o["stats"]["primary_rays"] == int(m.sum()) and o["stats"]["hit_rays"] == int((o["hit_id"][m] >= 0).sum())
+        assert n_px == W * H
+        assert np.array_equal(hit.reshape(H, W), whole["hit_id"]) and np.array_equal(rgb8.reshape(H, W, 3), whole["rgb8"])
+        assert np.array_equal(bits(lin.reshape(H, W, 3)), bits(whole["rgb_linear"])) and np.array_equal(bits(t.reshape(H, W)), bits(whole["t"]))
+
+
 def test_soup_scene_matches_oracle(srt, oracle):
     """Synthetic triangle soup (BASELINE config 5 generator) at a size the oracle finishes in seconds:
     4 objects, cross-object shadows, built by the oracle-side reference-free path."""

@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, block_rows, W, H, L, q):
+def _worker(rank, world, port, block_rows, W, H, L, q, block_cols=0):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,18 +30,19 @@ def _worker(rank, world, port, block_rows, W, H, L, q):
         from simple_raytracer_amd import abi, tiling
         g = gu.GoldenScene("cubes4_a0")
         lights = abi.light_staircase(g.light, L)
-        p = tiling.split_params(W, H, lights, rank, world, block_rows)
+        p = tiling.split_params(W, H, lights, rank, world, block_rows, block_cols)
         o = po.render(g.flat, p, n_threads=1)
-        assert tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu")).rows == o["rgb8"].shape[0]
-        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), frames=2)
-        fg.tile[0, : fg.rows].copy_(torch.from_numpy(o["rgb8"]))
-        fg.tile[1, : fg.rows].copy_(torch.from_numpy(255 - o["rgb8"]))
+        probe = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), block_cols=block_cols)
+        assert (probe.rows, probe.cols) == o["rgb8"].shape[:2]
+        fg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), frames=2, block_cols=block_cols)
+        fg.tile[0, : fg.rows, : fg.cols].copy_(torch.from_numpy(o["rgb8"]))
+        fg.tile[1, : fg.rows, : fg.cols].copy_(torch.from_numpy(255 - o["rgb8"]))
         frame = fg.gather()
         # two slots, gathers in flight while the next slot is filled (the overlap scheme of bench.py)
-        hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32, slots=2)
-        hg.tiles[0][0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"]))
+        hg = tiling.FrameGather(W, H, block_rows, rank, world, torch.device("cpu"), channels=1, dtype=torch.int32, slots=2, block_cols=block_cols)
+        hg.tiles[0][0, : hg.rows, : hg.cols, 0].copy_(torch.from_numpy(o["hit_id"]))
         hg.start(0)
-        hg.tiles[1][0, : hg.rows, :, 0].copy_(torch.from_numpy(o["hit_id"] + 7))
+        hg.tiles[1][0, : hg.rows, : hg.cols, 0].copy_(torch.from_numpy(o["hit_id"] + 7))
         hg.start(1)
         hits = hg.finish(0)
         if rank == 0:
@@ -60,14 +61,16 @@ def _worker(rank, world, port, block_rows, W, H, L, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,block_rows", [(2, 16), (2, 7), (3, 5)])
-def test_gather_reassembles_reference_frame(world, block_rows):
+@pytest.mark.parametrize("world,block_rows,block_cols", [(2, 16, 0), (2, 7, 0), (3, 5, 0), (2, 16, 32), (3, 8, 16), (4, 8, 24), (8, 8, 8)])
+def test_gather_reassembles_reference_frame(world, block_rows, block_cols):
+    """Scanline blocks (block_cols = 0) and tiles dealt in two dimensions (the column term of srt_params): tiles rendered per rank,
+    one gather, de-interleave on rank 0 = the reference's image.  (8 ranks: the world size of the target node.)"""
     import golden_util as gu
     W, H, L = 128, 96, 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, block_rows, W, H, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, block_rows, W, H, L, q, block_cols)) for r in range(world)]
     for p in procs:
         p.start()
     frame, hits = q.get(timeout=120)
