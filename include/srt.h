@@ -17,6 +17,7 @@
 #ifndef SRT_H
 #define SRT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -108,6 +109,14 @@ typedef struct srt_params {
     float    focal;                /* 400 (:506)                                                    */
     uint32_t n_lights;             /* lightAmount (:348,445)                                        */
     const float* light_pos;        /* n_lights x 3, host-accumulated staircase (:372-382)           */
+    /* NULL = the reference's frame: the scene has been transformed into camera space (main() applies inverse(viewMatrix) to every
+     * triangle each frame, simple_raytracer.cpp:558 etc.) and rays leave the origin.  Non-NULL = CAMERA MODE, an opt-in EXTENSION
+     * (SURVEY.md s8 f1): the scene and the light stay where they are, the hierarchy is built once, and the camera moves instead --
+     * 16 floats, column-major like glm::mat4, the matrix M that takes a camera-space ray into the scene's space (for the
+     * reference's scenes: M = the viewMatrix whose inverse main() applies to the triangles).  Ray origin = M[3].xyz, direction =
+     * (M[0] * dx + M[1] * dy) + M[2] * dz with (dx, dy, dz) the reference's (i, j, focal).  Same geometry, different rounding:
+     * results are pinned by the oracle run in the same mode, not by the reference. */
+    const float* ray_matrix;
     float    shadow_div;           /* 5   (:369)                                                    */
     float    reinhard;             /* 0.5 (:391)                                                    */
     float    gamma;                /* 1.1 (:396)                                                    */
@@ -159,6 +168,14 @@ uint32_t srt_cols_owned(const srt_params* p);
 int srt_scene_create(int device, const srt_scene_desc* desc, srt_scene** out);
 int srt_scene_destroy(srt_scene* s);
 
+/* The next frame's geometry into the SAME device allocations (the reference re-transforms and rebuilds everything per frame,
+ * simple_raytracer.cpp:534-618): `desc` must have the counts of the scene's current contents (n_objects, n_nodes, n_tris,
+ * n_textures, the same triangles textured / with normals), else SRT_ERR_LAYOUT -- create a new scene then.  Texture images are
+ * NOT re-uploaded (they rarely change between frames; tri_tex / tri_texcoord are).  Asynchronous on `stream`: the copies are
+ * ordered behind the renders already enqueued there (NULL = the scene's own stream, the one srt_render / srt_render_async use);
+ * the descriptor's arrays are only read during the call. */
+int srt_scene_update(srt_scene* s, const srt_scene_desc* desc, void* stream);
+
 /* Render into DEVICE buffers (rows = srt_rows_owned(p)); any output pointer may be NULL.
  *   d_hit_id     rows x W   int32   canonical triangle id, -1 = miss
  *   d_t          rows x W   f32     closest-hit distance (+inf on miss)
@@ -175,7 +192,15 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
 int srt_render(srt_scene* s, const srt_params* p,
                int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, srt_stats* stats);
 
-/* Wait for the last srt_render_device on this scene and collect its stats. */
+/* srt_render without the wait: the kernels and the copies into the host buffers are enqueued on the scene's own stream and the
+ * call returns; srt_sync() waits.  With buffers from srt_host_alloc (pinned memory) the copies are asynchronous and run at full
+ * PCIe rate; with ordinary memory they still work.  srt_scene_update(scene, desc, NULL) is ordered on the same stream, so
+ * "update, render_async, (build the next frame on the CPU), sync" keeps the GPU work off the host's critical path. */
+int srt_render_async(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8);
+void* srt_host_alloc(size_t bytes);        /* pinned host memory, NULL on failure */
+void  srt_host_free(void* p);
+
+/* Wait for the last srt_render_device / srt_render_async on this scene and collect its stats. */
 int srt_sync(srt_scene* s, srt_stats* stats);
 
 /* Device-resident size of the scene records and the per-record algorithmic byte sizes used by

@@ -241,8 +241,9 @@ static int anyhit_in_tree(const scene_view* s, int32_t node, v3 o, v3 d, work_ct
 
 /* shadowIntersection :321-342.  The reference also walks the hit object's own tree and discards
  * the result (:328 before :331); skipping it is result-neutral and is what is counted. */
-static int in_shadow(const scene_view* s, int32_t self_obj, v3 L, float t, v3 d, work_ctr* w) {
+static int in_shadow(const scene_view* s, int32_t self_obj, v3 L, float t, v3 d, work_ctr* w, int cam, v3 o) {
     v3 dt = v3scale(d, t);               /* ray.direction * fDistance            :325-326 */
+    if (cam) dt = v3add(o, dt);          /* camera mode (extension): the hit point of a ray that does not start at 0 */
     v3 sd = v3sub(L, dt), so = dt;
     for (uint32_t k = 0; k < s->d->n_objects; k++) {
         if ((int32_t)k == self_obj) continue;
@@ -281,6 +282,8 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
     uint64_t hits = 0, node_tests = 0, tri_tests = 0, snode_tests = 0, stri_tests = 0;
     /* sendRaysAndIntersectPointsColors:511-517: i = px + int(-W/2), dir = (i, j, focal), origin 0 */
     const int i0 = (int)(-(float)W / 2), j0 = (int)(-(float)H / 2);
+    const int cam = p->ray_matrix != NULL;       /* camera mode (extension, include/srt.h): rays go into the scene's space */
+    const float* M = p->ray_matrix;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : hits, node_tests, tri_tests, snode_tests, stri_tests, n_pixels)
@@ -293,7 +296,7 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
             if (x >= W) continue;                                    /* padding of a tile deal: not written */
             n_pixels++;
             const size_t pix = (size_t)r * WL + xl;
-            v3 o = v3make(0.0f, 0.0f, 0.0f);
+            v3 o = cam ? v3make(M[12], M[13], M[14]) : v3make(0.0f, 0.0f, 0.0f);
             v3 sum = v3make(0.f, 0.f, 0.f), tone = v3make(0.f, 0.f, 0.f);
             int32_t q[3] = { 0, 0, 0 };
             for (uint32_t ss = 0; ss < spp; ss++) {
@@ -302,6 +305,8 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
             const float sub_x = spp == 1 ? 0.0f : ((float)(ss % spp_n) + 0.5f) / (float)spp_n - 0.5f;
             const float sub_y = spp == 1 ? 0.0f : ((float)(ss / spp_n) + 0.5f) / (float)spp_n - 0.5f;
             v3 dir = v3make((float)(i0 + (int)x) + sub_x, (float)(j0 + (int)y) + sub_y, p->focal);
+            if (cam) dir = v3make((M[0] * dir.x + M[4] * dir.y) + M[8] * dir.z, (M[1] * dir.x + M[5] * dir.y) + M[9] * dir.z,
+                                  (M[2] * dir.x + M[6] * dir.y) + M[10] * dir.z);
             float best = INFINITY; int32_t best_id = -1;
             for (uint32_t k = 0; k < d->n_objects; k++)                      /* rayIntersection:409 */
                 closest_in_tree(&s, (int32_t)d->obj_root[k], o, dir, &best, &best_id, &w);
@@ -337,7 +342,7 @@ int oracle_render(const srt_scene_desc* d, const srt_params* p,
                 }
                 for (uint32_t l = 0; l < p->n_lights; l++) {                    /* softShadow:366-383 */
                     v3 L = v3make(p->light_pos[l * 3], p->light_pos[l * 3 + 1], p->light_pos[l * 3 + 2]);
-                    int sh_hit = in_shadow(&s, obj, L, best, dir, &ws);
+                    int sh_hit = in_shadow(&s, obj, L, best, dir, &ws, cam, o);
                     v3 c = phong(nrm, o, dir, L, color, ka, ks, sh, best);
                     if (sh_hit) c = v3make(c.x / p->shadow_div, c.y / p->shadow_div, c.z / p->shadow_div);   /* :369 */
                     ssum = v3add(ssum, c);                                       /* :370 */

@@ -40,7 +40,7 @@ class Params(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32),
         ("block_rows", C.c_uint32), ("block_first", C.c_uint32), ("block_stride", C.c_uint32), ("block_cols", C.c_uint32),
         ("focal", C.c_float),
-        ("n_lights", C.c_uint32), ("light_pos", _f32p),
+        ("n_lights", C.c_uint32), ("light_pos", _f32p), ("ray_matrix", _f32p),
         ("shadow_div", C.c_float), ("reinhard", C.c_float), ("gamma", C.c_float),
         ("background", C.c_uint8 * 4),
         ("spp", C.c_uint32), ("flags", C.c_uint32),
@@ -169,7 +169,7 @@ def light_staircase(base, n):
 
 def make_params(width, height, lights, *, block_rows=None, block_first=0, block_stride=1, block_cols=0,
                 focal=400.0, shadow_div=5.0, reinhard=0.5, gamma=1.1, background=REFERENCE_BACKGROUND,
-                spp=1, flags=0):
+                spp=1, flags=0, ray_matrix=None):
     """srt_params with the reference's literals; `lights` is an (n,3) f32 array kept alive on the
     returned object (attribute _lights)."""
     p = Params()
@@ -184,6 +184,10 @@ def make_params(width, height, lights, *, block_rows=None, block_first=0, block_
     p.shadow_div, p.reinhard, p.gamma = shadow_div, reinhard, gamma
     p.background[0], p.background[1], p.background[2], p.background[3] = background[0], background[1], background[2], 0
     p.spp, p.flags = spp, flags
+    if ray_matrix is not None:      # camera mode (extension): 16 floats, column-major
+        m = np.ascontiguousarray(np.asarray(ray_matrix, np.float32).reshape(16))
+        p.ray_matrix = _ptr(m, _f32p)
+        p._ray_matrix = m
     return p
 
 

@@ -1009,28 +1009,10 @@ FlatScene flattenScene(ObjectManager* om) {
 // ------------------------------------------------------------------------------------------------
 // Drop-in entry point and image output
 // ------------------------------------------------------------------------------------------------
-ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
-                                           int lightAmount, int device) {
-    FlatScene flat = flattenScene(objManager);
-    srt_scene_desc d = flat.desc();
-    srt_scene* scene = nullptr;
-    int rc = srt_scene_create(device, &d, &scene);
-    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_create: ") + srt_strerror(rc));
-    const uint32_t W = (uint32_t)imageSize.x, H = (uint32_t)imageSize.y;
-    srt_params p;
-    srt_params_default(&p, W, H);
-    std::vector<float> lights((size_t)lightAmount * 3);
-    const float base[3] = { lightPos.x, lightPos.y, lightPos.z };       // vec4 -> const vec3& drops w (:517 -> :405)
-    srt_light_staircase(base, (uint32_t)lightAmount, lights.data());
-    p.n_lights = (uint32_t)lightAmount; p.light_pos = lights.data();
-    const uint8_t key[3] = { 0, 0, 0 };                                  // ask for black so ImageData can skip it (:518)
-    p.background[0] = key[0]; p.background[1] = key[1]; p.background[2] = key[2];
-    std::vector<uint8_t> rgb8((size_t)W * H * 3);
-    rc = srt_render(scene, &p, nullptr, nullptr, nullptr, rgb8.data(), nullptr);
-    srt_scene_destroy(scene);
-    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_render: ") + srt_strerror(rc));
+// hit pixels of an 8-bit frame in the reference's emission order: x outer, y inner (:511-513).  Count per column, then fill the
+// slots in parallel.  Black = "not emitted" (:518).
+static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t H) {
     ImageData out;
-    // reference emission order: x outer, y inner (:511-513).  Count per column, then fill the slots in parallel.
     std::vector<size_t> col(W + 1, 0);
     parallel_for(W, 64, [&](size_t x0, size_t x1) {
         for (size_t x = x0; x < x1; x++) {
@@ -1055,6 +1037,84 @@ ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& li
         }
     });
     return out;
+}
+
+Renderer::Renderer(int device) : device_(device) {}
+Renderer::~Renderer() {
+    if (scene_) srt_scene_destroy(scene_);
+    if (rgb8_) srt_host_free(rgb8_);
+}
+
+// the ObjectManager's current state into the device scene: in place when the counts allow it, else a new scene
+void Renderer::upload(ObjectManager* objManager) {
+    FlatScene flat = flattenScene(objManager);
+    srt_scene_desc d = flat.desc();
+    int rc = scene_ ? srt_scene_update(scene_, &d, nullptr) : SRT_ERR_LAYOUT;
+    if (rc == SRT_ERR_LAYOUT) {
+        if (scene_) { srt_scene_destroy(scene_); scene_ = nullptr; }
+        rc = srt_scene_create(device_, &d, &scene_);
+        if (rc != SRT_OK) { scene_ = nullptr; throw std::runtime_error(std::string("srt_scene_create: ") + srt_strerror(rc)); }
+    } else if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_update: ") + srt_strerror(rc));
+}
+
+void Renderer::enqueue(const vec2& imageSize, const vec4& lightPos, int lightAmount, const mat4* viewMatrix) {
+    const uint32_t W = (uint32_t)imageSize.x, H = (uint32_t)imageSize.y;
+    const size_t bytes = (size_t)W * H * 3;
+    if (bytes > rgb8_bytes_) {
+        if (rgb8_) srt_host_free(rgb8_);
+        rgb8_ = (uint8_t*)srt_host_alloc(bytes);
+        rgb8_bytes_ = rgb8_ ? bytes : 0;
+        if (!rgb8_) throw std::runtime_error("srt_host_alloc failed");
+    }
+    srt_params p;
+    srt_params_default(&p, W, H);
+    std::vector<float> lights((size_t)lightAmount * 3);
+    const float base[3] = { lightPos.x, lightPos.y, lightPos.z };       // vec4 -> const vec3& drops w (:517 -> :405)
+    srt_light_staircase(base, (uint32_t)lightAmount, lights.data());
+    p.n_lights = (uint32_t)lightAmount; p.light_pos = lights.data();     // copied by the call
+    p.background[0] = p.background[1] = p.background[2] = 0;             // ask for black so that ImageData can skip it (:518)
+    float m16[16];
+    if (viewMatrix) { for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) m16[c * 4 + r] = (*viewMatrix)[c][r]; p.ray_matrix = m16; }
+    const int rc = srt_render_async(scene_, &p, nullptr, nullptr, nullptr, rgb8_);
+    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_render_async: ") + srt_strerror(rc));
+    W_ = W; H_ = H; pending_ = true;
+}
+
+void Renderer::submit(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount) {
+    if (pending_) throw std::runtime_error("Renderer::submit: collect() the previous frame first");
+    upload(objManager);
+    enqueue(imageSize, lightPos, lightAmount, nullptr);
+}
+
+ImageData Renderer::collect() {
+    if (!pending_) throw std::runtime_error("Renderer::collect: nothing submitted");
+    pending_ = false;
+    const int rc = srt_sync(scene_, nullptr);
+    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_sync: ") + srt_strerror(rc));
+    return image_data_from_rgb8(rgb8_, W_, H_);
+}
+
+ImageData Renderer::render(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount) {
+    submit(imageSize, lightPos, objManager, lightAmount);
+    return collect();
+}
+
+ImageData Renderer::renderFromCamera(const vec2& imageSize, const vec4& lightPosWorld, const mat4& viewMatrix, ObjectManager* objManager,
+                                     int lightAmount, bool sceneChanged) {
+    if (pending_) throw std::runtime_error("Renderer::renderFromCamera: collect() the previous frame first");
+    if (!scene_ || sceneChanged) upload(objManager);
+    enqueue(imageSize, lightPosWorld, lightAmount, &viewMatrix);
+    return collect();
+}
+
+ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
+                                           int lightAmount, int device) {
+    // one Renderer per thread and device, kept for the life of the thread (leaked on purpose: no HIP calls from thread-exit
+    // destructors): the second frame of an orbit re-uses the first frame's device scene and pinned buffers
+    static thread_local std::unordered_map<int, Renderer*> renderers;
+    Renderer*& r = renderers[device];
+    if (!r) r = new Renderer(device);
+    return r->render(imageSize, lightPos, objManager, lightAmount);
 }
 
 void writeBmp(const std::string& path, uint32_t W, uint32_t H, const uint8_t* rgb) {

@@ -146,6 +146,37 @@ struct ImageData { std::vector<vec2> imagePoints; std::vector<vec3> imageColors;
 ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
                                            int lightAmount = 1, int device = 0);
 
+// A device scene that outlives the frame.  The reference builds and drops everything per frame; its drop-in call above does the
+// same through a Renderer it keeps per thread and device, so that frame n + 1 re-uses frame n's device allocations
+// (srt_scene_update) and pinned buffers instead of paying hipMalloc / hipFree / pageable copies every frame.
+//   render()            = the drop-in call on this handle;
+//   submit() / collect() = the same in two halves: submit() flattens, uploads and enqueues the frame and returns, collect() waits
+//                         and builds the ImageData -- whatever the caller does in between (building the next frame's hierarchies)
+//                         overlaps with the GPU;
+//   renderFromCamera()  = CAMERA MODE (an extension, include/srt.h srt_params.ray_matrix): the scene stays in world space and is
+//                         uploaded only when `sceneChanged`; each frame passes the viewMatrix whose inverse the reference would
+//                         have applied to every triangle, and the light's WORLD position.
+class Renderer {
+public:
+    explicit Renderer(int device = 0);
+    ~Renderer();
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+    ImageData render(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount = 1);
+    void submit(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount = 1);
+    ImageData collect();
+    ImageData renderFromCamera(const vec2& imageSize, const vec4& lightPosWorld, const mat4& viewMatrix, ObjectManager* objManager,
+                               int lightAmount = 1, bool sceneChanged = false);
+private:
+    void upload(ObjectManager* objManager);
+    void enqueue(const vec2& imageSize, const vec4& lightPos, int lightAmount, const mat4* viewMatrix);
+    int device_;
+    srt_scene* scene_ = nullptr;
+    uint8_t* rgb8_ = nullptr; size_t rgb8_bytes_ = 0;      // pinned
+    uint32_t W_ = 0, H_ = 0;
+    bool pending_ = false;
+};
+
 // drawImage (:461-498) pixel contract: 8-bit RGB, every all-black pixel -> (173,216,230); written as
 // a 24-bit BMP like CImg::save_bmp.  displayImage is not supported (headless).
 void drawImage(const vec2& imgSize, const std::vector<vec2>& imagePoints, const std::vector<vec3>& imageColors,

@@ -27,13 +27,13 @@ int srth_om_add_object(void* om_, const char* name, uint32_t n, const float* poi
         ObjectManager* om = (ObjectManager*)om_;
         om->objColors[name] = vec3(1.f, 0.f, 0.f);
         om->objProperties[name] = vec3(0.2f, 0.5f, 15.0f);
-        std::vector<Triangle> tris(n);
+        std::vector<Triangle>& tris = om->objTriangles[name];      // filled in place: a 69 k-triangle object is 10 MB of Triangle
+        tris.clear(); tris.resize(n);
         for (uint32_t i = 0; i < n; i++) {
             const float* p = points + (size_t)i * 12;
             tris[i].pointOne = vec4(p[0], p[1], p[2], p[3]); tris[i].pointTwo = vec4(p[4], p[5], p[6], p[7]); tris[i].pointThree = vec4(p[8], p[9], p[10], p[11]);
             tris[i].color = vec3(1.f, 1.f, 1.f);
         }
-        om->setTriangles(name, tris);
     })
 }
 // Array-fed textured object: the state loadObjFile leaves for a textured mesh (Object.cpp:98-161)
@@ -165,5 +165,42 @@ void srth_mat_view(const float* pos, const float* rot, float* m) { from_mat(Tran
 void srth_mat_inverse(const float* a, float* m) { from_mat(inverse(to_mat(a)), m); }
 void srth_mat_mul(const float* a, const float* b, float* m) { from_mat(to_mat(a) * to_mat(b), m); }
 void srth_mat_mul_vec4(const float* a, const float* v, float* out) { vec4 r = to_mat(a) * vec4(v[0], v[1], v[2], v[3]); std::memcpy(out, &r.x, 16); }
+
+// ---- Renderer: a device scene kept across frames (srt_host.h) ------------------------------------------------------------
+void* srth_renderer_new(int device) { try { return new Renderer(device); } catch (...) { return nullptr; } }
+void srth_renderer_free(void* r) { delete (Renderer*)r; }
+static int64_t image_to_dense(const ImageData& d, uint32_t W, uint32_t H, float* rgb) {
+    std::memset(rgb, 0, (size_t)W * H * 3 * sizeof(float));
+    for (size_t i = 0; i < d.imagePoints.size(); i++) {
+        const size_t x = (size_t)d.imagePoints[i].x, y = (size_t)d.imagePoints[i].y;
+        float* c = rgb + (y * W + x) * 3;
+        c[0] = d.imageColors[i].x; c[1] = d.imageColors[i].y; c[2] = d.imageColors[i].z;
+    }
+    return (int64_t)d.imagePoints.size();
+}
+// rgb = NULL: the frame is rendered and collected but not written out densely (timing runs)
+int64_t srth_renderer_render(void* r, void* om, uint32_t W, uint32_t H, const float* light4, int light_amount, float* rgb) {
+    try {
+        ImageData d = ((Renderer*)r)->render(vec2((float)W, (float)H), vec4(light4[0], light4[1], light4[2], light4[3]), (ObjectManager*)om, light_amount);
+        return rgb ? image_to_dense(d, W, H, rgb) : (int64_t)d.imagePoints.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int srth_renderer_submit(void* r, void* om, uint32_t W, uint32_t H, const float* light4, int light_amount) {
+    GUARD(((Renderer*)r)->submit(vec2((float)W, (float)H), vec4(light4[0], light4[1], light4[2], light4[3]), (ObjectManager*)om, light_amount))
+}
+int64_t srth_renderer_collect(void* r, uint32_t W, uint32_t H, float* rgb) {
+    try {
+        ImageData d = ((Renderer*)r)->collect();
+        return rgb ? image_to_dense(d, W, H, rgb) : (int64_t)d.imagePoints.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int64_t srth_renderer_render_from_camera(void* r, void* om, uint32_t W, uint32_t H, const float* light4_world, const float* view16, int light_amount,
+                                         int scene_changed, float* rgb) {
+    try {
+        ImageData d = ((Renderer*)r)->renderFromCamera(vec2((float)W, (float)H), vec4(light4_world[0], light4_world[1], light4_world[2], light4_world[3]),
+                                                      to_mat(view16), (ObjectManager*)om, light_amount, scene_changed != 0);
+        return rgb ? image_to_dense(d, W, H, rgb) : (int64_t)d.imagePoints.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 
 } // extern "C"

@@ -66,6 +66,9 @@ struct srt_scene {
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
     char pipeline[96] = "";                       // kernels of the last render, in launch order
+    uint32_t n_textures = 0; bool has_tex = false;
+    void* stage = nullptr; size_t stage_bytes = 0; hipEvent_t staged = nullptr;      // pinned staging of srt_scene_update
+    hipStream_t stream = nullptr;                 // the scene's own stream (srt_render, srt_render_async, srt_scene_update with stream NULL)
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
     uint32_t* ws_qlist = nullptr; uint32_t* d_qcount = nullptr; uint32_t qcap = 0;      // quadrants with hits: 64 shard lists of qcap entries, their counters
     double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
@@ -147,6 +150,7 @@ void srt_params_default(srt_params* p, uint32_t width, uint32_t height) {
     p->focal = 400.0f;                 // simple_raytracer.cpp:506
     p->n_lights = 1;                   // :445
     p->light_pos = nullptr;
+    p->ray_matrix = nullptr;           // the reference's frame: scene in camera space, rays from the origin
     p->shadow_div = 5.0f;              // :369
     p->reinhard = 0.5f;                // :391
     p->gamma = 1.1f;                   // :396
@@ -216,6 +220,9 @@ int srt_scene_destroy(srt_scene* s) {
     if (s->ws_shadow) (void)hipFree(s->ws_shadow);
     if (s->ws_qlist) (void)hipFree(s->ws_qlist);
     if (s->d_qcount) (void)hipFree(s->d_qcount);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->stage) (void)hipHostFree(s->stage);
+    if (s->staged) (void)hipEventDestroy(s->staged);
     if (s->ws_acc) (void)hipFree(s->ws_acc);
     if (s->ws_sub) (void)hipFree(s->ws_sub);
     if (s->ws_sub_hit) (void)hipFree(s->ws_sub_hit);
@@ -229,31 +236,31 @@ int srt_scene_destroy(srt_scene* s) {
     return SRT_OK;
 }
 
-// Validate the layout contract and rewrite the trees in DFS pre-order with skip links.
-static int build_device_records(const srt_scene_desc* d, std::vector<DevNode>& nodes, std::vector<int2>& ranges) {
+// Validate the layout contract and rewrite the trees in DFS pre-order with skip links: nodes[n_nodes], ranges[n_objects].
+static int build_device_records(const srt_scene_desc* d, DevNode* nodes, int2* ranges) {
     const uint32_t N = d->n_nodes;
-    nodes.clear(); nodes.reserve(N); ranges.resize(d->n_objects);
     std::vector<uint8_t> seen(N, 0);
     int64_t tri_cursor = 0;
+    uint32_t cursor = 0;                   // nodes emitted so far
     // explicit DFS stack: state 0 = emit node, 1 = left subtree done, 2 = right subtree done
     struct Item { int32_t orig; int32_t emitted; int state; };
     std::vector<Item> st;
     for (uint32_t k = 0; k < d->n_objects; k++) {
         const uint32_t root = d->obj_root[k];
         if (root >= N) return SRT_ERR_LAYOUT;
-        ranges[k].x = (int32_t)nodes.size();
+        ranges[k].x = (int32_t)cursor;
         st.clear(); st.push_back({ (int32_t)root, -1, 0 });
         while (!st.empty()) {
             Item& it = st.back();        // not used after a push_back below
             if (it.state == 0) {
-                if (it.orig < 0 || (uint32_t)it.orig >= N || seen[it.orig]) return SRT_ERR_LAYOUT;
+                if (it.orig < 0 || (uint32_t)it.orig >= N || seen[it.orig] || cursor >= N) return SRT_ERR_LAYOUT;
                 seen[it.orig] = 1;
                 const int32_t l = d->node_left[it.orig], r = d->node_right[it.orig];
                 DevNode dn;
                 dn.minx = d->node_min[3 * (size_t)it.orig]; dn.miny = d->node_min[3 * (size_t)it.orig + 1]; dn.minz = d->node_min[3 * (size_t)it.orig + 2];
                 dn.maxx = d->node_max[3 * (size_t)it.orig]; dn.maxy = d->node_max[3 * (size_t)it.orig + 1]; dn.maxz = d->node_max[3 * (size_t)it.orig + 2];
                 dn.skip = -1; dn.leaf = -1;
-                it.emitted = (int32_t)nodes.size();
+                it.emitted = (int32_t)cursor;
                 if (l < 0 && r < 0) {
                     const int32_t first = d->node_first[it.orig], cnt = d->node_count[it.orig];
                     if (cnt < 0 || (cnt > 0 && first != tri_cursor) || tri_cursor + cnt > (int64_t)d->n_tris) return SRT_ERR_LAYOUT;
@@ -262,33 +269,84 @@ static int build_device_records(const srt_scene_desc* d, std::vector<DevNode>& n
                     dn.leaf = (int32_t)((tri_cursor << LEAF_SHIFT) | cnt);
                     tri_cursor += cnt;
                     dn.skip = it.emitted + 1;
-                    nodes.push_back(dn);
+                    nodes[cursor++] = dn;
                     st.pop_back();
                 } else {
                     if (l < 0 || r < 0) return SRT_ERR_LAYOUT;      // the reference's trees are full binary
-                    nodes.push_back(dn);
+                    nodes[cursor++] = dn;
                     it.state = 1;
                     st.push_back({ l, -1, 0 });
                 }
             } else if (it.state == 1) {
                 it.state = 2;
                 const int32_t r = d->node_right[it.orig];
-                nodes[it.emitted].leaf = ~(int32_t)nodes.size();     // inner node: ~(pre-order index of the right child) < 0
+                nodes[it.emitted].leaf = ~(int32_t)cursor;           // inner node: ~(pre-order index of the right child) < 0
                 st.push_back({ r, -1, 0 });
             } else {
-                nodes[it.emitted].skip = (int32_t)nodes.size();
+                nodes[it.emitted].skip = (int32_t)cursor;
                 st.pop_back();
             }
         }
-        ranges[k].y = (int32_t)nodes.size();
+        ranges[k].y = (int32_t)cursor;
     }
-    if (nodes.size() != N || tri_cursor != (int64_t)d->n_tris) return SRT_ERR_LAYOUT;
+    if (cursor != N || tri_cursor != (int64_t)d->n_tris) return SRT_ERR_LAYOUT;
     return SRT_OK;
 }
 
-static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** out) {
-    if (!d || !out) return SRT_ERR_ARG;
-    *out = nullptr;
+// How many slab tests does a ray cost?  Surface-area estimate: a random line that crosses the scene's bounds crosses a convex
+// box inside them with probability area(box) / area(bounds), and a node is tested when its parent's box is crossed.  A good
+// hierarchy gives a few dozen (bunny: boxes shrink with depth); a median split by first vertex of a random soup gives hundreds
+// to thousands (boxes stay as wide as the scene in two axes).  In the second case neighbouring rays test nearly the same nodes
+// and the packet walk (srt_packet.h) wins for primary rays as well.
+static double overlap_estimate(const DevNode* nodes, uint32_t n_nodes, const int2* ranges, uint32_t n_objects) {
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    auto area = [](const float* a, const float* b) -> double {
+        const double x = (double)b[0] - a[0], y = (double)b[1] - a[1], z = (double)b[2] - a[2];
+        return (x < 0 || y < 0 || z < 0) ? 0. : x * y + y * z + z * x;
+    };
+    for (uint32_t k = 0; k < n_objects; k++) {
+        const DevNode& n = nodes[ranges[k].x];
+        const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
+        if (area(mn, mx) <= 0.) continue;
+        for (int a = 0; a < 3; a++) { lo[a] = mn[a] < lo[a] ? mn[a] : lo[a]; hi[a] = mx[a] > hi[a] ? mx[a] : hi[a]; }
+    }
+    const double total = area(lo, hi);
+    if (!(total > 0.)) return 0.;
+    double sum = 0.;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const DevNode& n = nodes[i];
+        if (n.leaf >= 0) continue;                       // the children of an inner node are tested when its box is crossed
+        const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
+        sum += 2. * area(mn, mx);
+    }
+    return (double)n_objects + sum / total;              // + every root
+}
+
+// per-triangle records: independent, so big scenes are cut over a few host threads (a scene made per frame by a drop-in
+// caller spends more time here than in the render)
+static void derive_triangles(const srt_scene_desc* d, DevTri* tris, DevTriO* tris_o) {
+    auto derive_range = [&](uint32_t b, uint32_t e) {
+        for (uint32_t i = b; i < e; i++) { tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i); tris_o[i] = derive_triangle_origin(tris[i]); }
+    };
+    const uint32_t n = d->n_tris;
+    unsigned hc = std::thread::hardware_concurrency();
+    const uint32_t T = n < 32768 ? 1u : (hc >= 8 ? 8u : (hc >= 2 ? hc : 1u));
+    if (T == 1) { derive_range(0, n); return; }
+    std::vector<std::thread> th;
+    const uint32_t step = (n + T - 1) / T;
+    for (uint32_t k = 1; k < T; k++) th.emplace_back(derive_range, k * step < n ? k * step : n, (k + 1) * step < n ? (k + 1) * step : n);
+    derive_range(0, step < n ? step : n);
+    for (std::thread& t : th) t.join();
+}
+
+// first triangle of each object (the layout contract makes tri_obj non-decreasing): first[n_objects + 1]
+static void derive_tri_first(const srt_scene_desc* d, int32_t* first) {
+    for (uint32_t k = 0; k <= d->n_objects; k++) first[k] = (int32_t)d->n_tris;
+    for (uint32_t i = d->n_tris; i-- > 0;) first[d->tri_obj[i]] = (int32_t)i;
+    for (uint32_t k = d->n_objects; k-- > 0;) if (first[k] > first[k + 1]) first[k] = first[k + 1];      // objects without triangles
+}
+
+static int check_desc(const srt_scene_desc* d) {
     if (!d->n_objects || !d->n_nodes || !d->node_min || !d->node_max || !d->node_left || !d->node_right ||
         !d->node_first || !d->node_count || !d->obj_root || !d->obj_color || !d->obj_material) return SRT_ERR_ARG;
     if (d->n_tris && (!d->tri_points || !d->tri_obj)) return SRT_ERR_ARG;
@@ -300,59 +358,23 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
         if (d->tri_obj[i] < 0 || (uint32_t)d->tri_obj[i] >= d->n_objects) return SRT_ERR_LAYOUT;
         if (d->tri_tex && d->tri_tex[i] >= (int32_t)d->n_textures) return SRT_ERR_TEXTURE;
     }
+    return SRT_OK;
+}
+
+static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** out) {
+    if (!d || !out) return SRT_ERR_ARG;
+    *out = nullptr;
+    int rc = check_desc(d);
+    if (rc != SRT_OK) return rc;
     // host-side records first (validates the layout contract; pure CPU work), then the device
     alloc_gate();
-    std::vector<DevNode> nodes; std::vector<int2> ranges;
-    int rc = build_device_records(d, nodes, ranges);
+    std::vector<DevNode> nodes(d->n_nodes); std::vector<int2> ranges(d->n_objects);
+    rc = build_device_records(d, nodes.data(), ranges.data());
     if (rc != SRT_OK) return rc;
-    // How many slab tests does a ray cost?  Surface-area estimate: a random line that crosses the scene's bounds crosses a
-    // convex box inside them with probability area(box) / area(bounds), and a node is tested when its parent's box is
-    // crossed.  A good hierarchy gives a few dozen (bunny: boxes shrink with depth); a median split by first vertex of a
-    // random soup gives thousands (boxes stay as wide as the scene in two axes).  In the second case neighbouring rays
-    // test nearly the same nodes and the packet walk (srt_packet.h) wins for primary rays as well.
-    double overlap = 0.;
-    {
-        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-        auto area = [](const float* a, const float* b) -> double {
-            const double x = (double)b[0] - a[0], y = (double)b[1] - a[1], z = (double)b[2] - a[2];
-            return (x < 0 || y < 0 || z < 0) ? 0. : x * y + y * z + z * x;
-        };
-        for (const int2& r : ranges) {
-            const DevNode& n = nodes[r.x];
-            const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
-            if (area(mn, mx) <= 0.) continue;
-            for (int a = 0; a < 3; a++) { lo[a] = mn[a] < lo[a] ? mn[a] : lo[a]; hi[a] = mx[a] > hi[a] ? mx[a] : hi[a]; }
-        }
-        const double total = area(lo, hi);
-        if (total > 0.) {
-            double sum = 0.;
-            for (const DevNode& n : nodes) {
-                if (n.leaf >= 0) continue;                       // the children of an inner node are tested when its box is crossed
-                const float mn[3] = { n.minx, n.miny, n.minz }, mx[3] = { n.maxx, n.maxy, n.maxz };
-                sum += 2. * area(mn, mx);
-            }
-            overlap = (double)ranges.size() + sum / total;      // + every root
-        }
-    }
+    const double overlap = overlap_estimate(nodes.data(), d->n_nodes, ranges.data(), d->n_objects);
     std::vector<DevTri> tris(d->n_tris);
     std::vector<DevTriO> tris_o(d->n_tris);
-    {   // per-triangle records: independent, so big scenes are cut over a few host threads (a scene made per frame by a
-        // drop-in caller spends more time here than in the render)
-        auto derive_range = [&](uint32_t b, uint32_t e) {
-            for (uint32_t i = b; i < e; i++) { tris[i] = derive_triangle(d->tri_points + 12 * (size_t)i); tris_o[i] = derive_triangle_origin(tris[i]); }
-        };
-        const uint32_t n = d->n_tris;
-        unsigned hc = std::thread::hardware_concurrency();
-        const uint32_t T = n < 32768 ? 1u : (hc >= 8 ? 8u : (hc >= 2 ? hc : 1u));
-        if (T == 1) derive_range(0, n);
-        else {
-            std::vector<std::thread> th;
-            const uint32_t step = (n + T - 1) / T;
-            for (uint32_t k = 1; k < T; k++) th.emplace_back(derive_range, k * step < n ? k * step : n, (k + 1) * step < n ? (k + 1) * step : n);
-            derive_range(0, step < n ? step : n);
-            for (std::thread& t : th) t.join();
-        }
-    }
+    derive_triangles(d, tris.data(), tris_o.data());
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SRT_ERR_NO_GPU;
@@ -367,10 +389,9 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
     UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
     UP(upload(s, ranges.data(), ranges.size(), &s->dev.obj_range));
-    {   // first triangle of each object (the layout contract makes tri_obj non-decreasing)
-        std::vector<int32_t> first(d->n_objects + 1, (int32_t)d->n_tris);
-        for (uint32_t i = d->n_tris; i-- > 0;) first[d->tri_obj[i]] = (int32_t)i;
-        for (uint32_t k = d->n_objects; k-- > 0;) if (first[k] > first[k + 1]) first[k] = first[k + 1];      // objects without triangles
+    {
+        std::vector<int32_t> first(d->n_objects + 1);
+        derive_tri_first(d, first.data());
         UP(upload(s, first.data(), first.size(), &s->dev.obj_tri_first));
     }
     UP(upload(s, d->obj_color, (size_t)d->n_objects * 3, &s->dev.obj_color));
@@ -396,6 +417,7 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     }
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
+    s->n_textures = d->n_textures; s->has_tex = any_tex;
     s->overlap = overlap;
     s->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
     hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
@@ -415,6 +437,69 @@ int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
     return guarded([&] { return scene_create_impl(device, d, out); });
 }
 
+// New geometry into the EXISTING device allocations: the reference re-transforms every triangle and rebuilds every hierarchy per
+// frame (simple_raytracer.cpp:534-618), so a drop-in caller hands over a new flat scene per frame -- with the same counts (the
+// builder's tree shape depends only on the triangle count).  Records are derived straight into one pinned staging block and go
+// to the device with asynchronous copies on `stream`: no hipMalloc / hipFree, no pageable copy, no synchronisation with the
+// renders already enqueued on that stream (the copies are ordered behind them).
+static int own_stream(srt_scene* s, hipStream_t* out);
+static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t stream) {
+    if (!s || !d) return SRT_ERR_ARG;
+    int rc = check_desc(d);
+    if (rc != SRT_OK) return rc;
+    if (!stream) { rc = own_stream(s, &stream); if (rc != SRT_OK) return rc; }
+    bool any_tex = false;
+    if (d->n_textures && d->tri_tex) for (uint32_t i = 0; i < d->n_tris; i++) any_tex |= d->tri_tex[i] >= 0;
+    if (d->n_objects != s->dev.n_objects || d->n_nodes != s->dev.n_nodes || d->n_tris != s->dev.n_tris || d->n_textures != s->n_textures ||
+        any_tex != s->has_tex || (d->tri_normals != nullptr) != (s->dev.tri_normals != nullptr)) return SRT_ERR_LAYOUT;      // counts differ: create a new scene
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nN = d->n_nodes, nT = d->n_tris, nO = d->n_objects;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_nodes = 0, o_tris = o_nodes + pad(nN * sizeof(DevNode)), o_triso = o_tris + pad(nT * sizeof(DevTri)),
+                 o_triobj = o_triso + pad(nT * sizeof(DevTriO)), o_ranges = o_triobj + pad(nT * 4), o_first = o_ranges + pad(nO * sizeof(int2)),
+                 o_color = o_first + pad((nO + 1) * 4), o_mat = o_color + pad(nO * 12), o_nrm = o_mat + pad(nO * 12),
+                 o_tex = o_nrm + pad(d->tri_normals ? nT * 36 : 0), o_tc = o_tex + pad(any_tex ? nT * 4 : 0), total = o_tc + pad(any_tex ? nT * 24 : 0);
+    if (s->stage_bytes < total) {
+        if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&s->stage, total, hipHostMallocDefault));
+        s->stage_bytes = total;
+        if (!s->staged) HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipEventSynchronize(s->staged));               // the previous update's copies have left the staging block
+    }
+    char* h = (char*)s->stage;
+    DevNode* nodes = (DevNode*)(h + o_nodes); int2* ranges = (int2*)(h + o_ranges);
+    rc = build_device_records(d, nodes, ranges);
+    if (rc != SRT_OK) return rc;
+    derive_triangles(d, (DevTri*)(h + o_tris), (DevTriO*)(h + o_triso));
+    derive_tri_first(d, (int32_t*)(h + o_first));
+    std::memcpy(h + o_triobj, d->tri_obj, nT * 4);
+    std::memcpy(h + o_color, d->obj_color, nO * 12);
+    std::memcpy(h + o_mat, d->obj_material, nO * 12);
+    if (d->tri_normals) std::memcpy(h + o_nrm, d->tri_normals, nT * 36);
+    if (any_tex) { std::memcpy(h + o_tex, d->tri_tex, nT * 4); std::memcpy(h + o_tc, d->tri_texcoord, nT * 24); }
+    #define CP(dst, off, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync((void*)(dst), h + (off), (bytes), hipMemcpyHostToDevice, stream)); } while (0)
+    CP(s->dev.nodes, o_nodes, nN * sizeof(DevNode));
+    CP(s->dev.tris, o_tris, nT * sizeof(DevTri));
+    CP(s->dev.tris_o, o_triso, nT * sizeof(DevTriO));
+    CP(s->dev.tri_obj, o_triobj, nT * 4);
+    CP(s->dev.obj_range, o_ranges, nO * sizeof(int2));
+    CP(s->dev.obj_tri_first, o_first, (nO + 1) * 4);
+    CP(s->dev.obj_color, o_color, nO * 12);
+    CP(s->dev.obj_mat, o_mat, nO * 12);
+    if (d->tri_normals) CP(s->dev.tri_normals, o_nrm, nT * 36);
+    if (any_tex) { CP(s->dev.tri_tex, o_tex, nT * 4); CP(s->dev.tri_tc, o_tc, nT * 24); }
+    #undef CP
+    HIP_TRY(hipEventRecord(s->staged, stream));
+    s->overlap = overlap_estimate(nodes, d->n_nodes, ranges, d->n_objects);
+    s->prefer_packet = s->overlap > PACKET_OVERLAP_THRESHOLD;
+    return SRT_OK;
+}
+
+int srt_scene_update(srt_scene* s, const srt_scene_desc* d, void* stream) {
+    return guarded([&] { return scene_update_impl(s, d, (hipStream_t)stream); });
+}
+
 void srt_debug_fail_host_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
@@ -425,6 +510,7 @@ static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) 
 
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
+    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22)) return SRT_ERR_ARG;      // camera mode: shipped pipeline only
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     if (p->block_cols && ((p->block_cols & 7u) || (p->block_rows & 7u) || p->block_first >= p->block_stride)) return SRT_ERR_ARG;   // tiles of whole 8x8 pixel blocks
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
@@ -497,6 +583,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     DevParams dp;
     dp.smooth = (p->flags & SRT_FLAG_SMOOTH_NORMALS) ? 1u : 0u;
     dp.shadow_px_major = 0u;
+    dp.cam = p->ray_matrix ? 1u : 0u;
+    for (int c = 0; c < 4; c++) for (int r3 = 0; r3 < 3; r3++) dp.cm[c * 3 + r3] = p->ray_matrix ? p->ray_matrix[c * 4 + r3] : 0.0f;
     dp.xcd_rows = (s->bytes > (32ull << 20) || variant_of(p) == 18) ? 1u : 0u;       // records far beyond one XCD's 4 MiB L2 (variant 18: forced, for the tests)
     dp.W = wl; dp.Wimg = p->width; dp.col_block = p->block_cols; dp.H = p->height; dp.rows = rows;
     dp.block_rows = p->block_rows; dp.block_first = p->block_first; dp.block_stride = p->block_stride;
@@ -576,8 +664,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         //                scene), 1..7 light samples, or variant 23
         //   pk + pk      both packet kernels: such scenes with 8+ light samples, or variant 22
         //   nq chunked   the round-1 form for 8+ samples (k_shadow_nq, 64 rays in flight, samples cut over blockIdx.z): variant 20
-        const bool pk_closest = variant == 22 || variant == 23 || (variant == 0 && s->prefer_packet && !force_nq);
-        const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
+        // camera mode (rays that do not start at the origin) runs on the packet kernels, which take a general ray
+        const bool pk_closest = fp.cam || variant == 22 || variant == 23 || (variant == 0 && s->prefer_packet && !force_nq);
+        const bool pk_shadow = p->n_lights && (fp.cam || variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
@@ -597,7 +686,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         default:
             if (pk_closest) {          // one wavefront per 8x8 tile walks the trees in lock step; a workgroup = 2 x 2 tiles
                 const dim3 gp((grid8.x + 1) / 2, fp.xcd_rows ? ((grid8.y + 1) / 2 + 7) / 8 * 8 : (grid8.y + 1) / 2);
-                if (count)            hipLaunchKernelGGL((k_closest_hit_pk<true, true, false>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+                if (fp.cam && count)  hipLaunchKernelGGL((k_closest_hit_pk<true, true, false, true>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+                else if (fp.cam)      hipLaunchKernelGGL((k_closest_hit_pk<false, true, false, true>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+                else if (count)       hipLaunchKernelGGL((k_closest_hit_pk<true, true, false>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else if (fp.xcd_rows) hipLaunchKernelGGL((k_closest_hit_pk<false, true, true>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else                  hipLaunchKernelGGL((k_closest_hit_pk<false, true, false>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
             } else if (fused) {        // closest hit + shadow rays in one launch
@@ -731,11 +822,21 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
     return SRT_OK;
 }
 
-int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, srt_stats* stats) {
+// The scene's own stream: srt_render / srt_render_async / srt_scene_update(stream = NULL) are ordered on it.
+static int own_stream(srt_scene* s, hipStream_t* out) {
+    if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    *out = s->stream;
+    return SRT_OK;
+}
+
+static int render_async_impl(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, bool wait, srt_stats* stats) {
     if (!s) return SRT_ERR_ARG;
     int rc = check_params(p);
     if (rc != SRT_OK) return rc;
     HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st;
+    rc = own_stream(s, &st);
+    if (rc != SRT_OK) return rc;
     const uint32_t rows = srt_rows_owned(p);
     const size_t pixels = (size_t)srt_cols_owned(p) * rows;
     if (pixels > s->ws_out_pixels) {
@@ -747,18 +848,42 @@ int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, flo
         HIP_TRY(hipMalloc((void**)&s->ws_rgb8, pixels * 3));
         s->ws_out_pixels = pixels;
     }
-    rc = srt_render_device(s, p, nullptr, nullptr, nullptr, rgb_linear ? s->ws_lin : nullptr, rgb8 ? s->ws_rgb8 : nullptr);
+    rc = render_device_impl(s, p, st, nullptr, nullptr, rgb_linear ? s->ws_lin : nullptr, rgb8 ? s->ws_rgb8 : nullptr);
     if (rc != SRT_OK) return rc;
-    rc = srt_sync(s, stats);
-    if (rc != SRT_OK) return rc;
-    if (pixels) {
-        if (hit_id) HIP_TRY(hipMemcpy(hit_id, s->ws_hit, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (t) HIP_TRY(hipMemcpy(t, s->ws_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
-        if (rgb_linear) HIP_TRY(hipMemcpy(rgb_linear, s->ws_lin, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        if (rgb8) HIP_TRY(hipMemcpy(rgb8, s->ws_rgb8, pixels * 3, hipMemcpyDeviceToHost));
+    if (wait) {        // srt_render: the caller's buffers are ordinary (pageable) memory as a rule, where a synchronous copy is the fast one
+        rc = srt_sync(s, stats);
+        if (rc != SRT_OK) return rc;
+        if (pixels) {
+            if (hit_id) HIP_TRY(hipMemcpy(hit_id, s->ws_hit, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (t) HIP_TRY(hipMemcpy(t, s->ws_t, pixels * sizeof(float), hipMemcpyDeviceToHost));
+            if (rgb_linear) HIP_TRY(hipMemcpy(rgb_linear, s->ws_lin, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            if (rgb8) HIP_TRY(hipMemcpy(rgb8, s->ws_rgb8, pixels * 3, hipMemcpyDeviceToHost));
+        }
+        return SRT_OK;
+    }
+    if (pixels) {      // device -> host behind the kernels; truly asynchronous into pinned memory (srt_host_alloc)
+        if (hit_id) HIP_TRY(hipMemcpyAsync(hit_id, s->ws_hit, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (t) HIP_TRY(hipMemcpyAsync(t, s->ws_t, pixels * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (rgb_linear) HIP_TRY(hipMemcpyAsync(rgb_linear, s->ws_lin, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, s->ws_rgb8, pixels * 3, hipMemcpyDeviceToHost, st));
     }
     return SRT_OK;
 }
+
+int srt_render_async(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8) {
+    return guarded([&] { return render_async_impl(s, p, hit_id, t, rgb_linear, rgb8, false, nullptr); });
+}
+
+int srt_render(srt_scene* s, const srt_params* p, int32_t* hit_id, float* t, float* rgb_linear, uint8_t* rgb8, srt_stats* stats) {
+    return guarded([&] { return render_async_impl(s, p, hit_id, t, rgb_linear, rgb8, true, stats); });
+}
+
+void* srt_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void srt_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- known-answer entry points (device leaf functions on caller vectors; host pointers in and out) ----
 namespace {

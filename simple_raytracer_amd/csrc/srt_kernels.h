@@ -45,6 +45,8 @@ struct DevParams {
     uint32_t smooth;              // interpolateNormal mode (simple_raytracer.cpp:132-140,162)
     uint32_t xcd_rows;            // host-side choice of the k_trace_nq build that deals whole tile rows to XCDs
     uint32_t shadow_px_major;     // shadow bits as the packet shadow kernel writes them: per pixel one u64 per 64 light samples
+    uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
+    float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
 };
 
 // counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
@@ -88,9 +90,16 @@ __device__ __forceinline__ uint32_t image_col(const DevParams& p, uint32_t px, u
 __device__ __forceinline__ bool pixel_live(const DevParams& p, uint32_t px, uint32_t r) {
     return px < p.W && r < p.rows && (!p.col_block || image_col(p, px, r) < p.Wimg);
 }
-// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = x + int(-W/2); px = LOCAL column, y = image row
+// sendRaysAndIntersectPointsColors:511-517: dir = (i, j, focal), i = x + int(-W/2); px = LOCAL column, y = image row.
+// Camera mode (extension): the same ray in the scene's space, (M[0] * dx + M[1] * dy) + M[2] * dz, leaving M[3].xyz.
 __device__ __forceinline__ V3 primary_dir(const DevParams& p, uint32_t px, uint32_t y) {
-    return mk((float)(p.i0 + (int)image_col(p, px, y)) + p.sub_x, (float)(p.j0 + (int)y) + p.sub_y, p.focal);
+    const V3 d = mk((float)(p.i0 + (int)image_col(p, px, y)) + p.sub_x, (float)(p.j0 + (int)y) + p.sub_y, p.focal);
+    if (!p.cam) return d;
+    return mk((p.cm[0] * d.x + p.cm[3] * d.y) + p.cm[6] * d.z, (p.cm[1] * d.x + p.cm[4] * d.y) + p.cm[7] * d.z,
+              (p.cm[2] * d.x + p.cm[5] * d.y) + p.cm[8] * d.z);
+}
+__device__ __forceinline__ V3 ray_origin(const DevParams& p) {
+    return p.cam ? mk(p.cm[9], p.cm[10], p.cm[11]) : mk(0.0f, 0.0f, 0.0f);
 }
 
 // 16x16 pixel tile per 256-thread workgroup, one 8x8 sub-tile per wavefront: the 64 primary rays of
@@ -1054,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
     if (id < 0) return;
     const size_t tile_index = (size_t)(blockIdx.y * 2 + (wave >> 1)) * ((p.W + 7) / 8) + blockIdx.x * 2 + (wave & 1);   // 8x8 tile
     const float t = t_in[pix];
-    const V3 o = mk(0.0f, 0.0f, 0.0f);
+    const V3 o = ray_origin(p);
     const V3 d = primary_dir(p, px, image_row(p, r));
     const int32_t obj = s.tri_obj[id];
     const float4* tp = reinterpret_cast<const float4*>(s.tris) + (size_t)id * 3;

@@ -169,11 +169,12 @@ __device__ __forceinline__ bool packet_any_hit_win(const DevScene& s, bool valid
 }
 
 // ---- closest-hit packet walk for rays from the origin (rayIntersection:405-431) ------------------------------------------
-template <bool COUNT, bool FILTER>
-__device__ __forceinline__ void packet_closest_hit(const DevScene& s, bool valid, V3 d, float& best, int32_t& best_id,
+// WORLD: camera mode -- the rays leave `o` instead of the origin, so the test reads the general triangle record (P1, e1, e2)
+template <bool COUNT, bool FILTER, bool WORLD>
+__device__ __forceinline__ void packet_closest_hit(const DevScene& s, bool valid, V3 o_in, V3 d, float& best, int32_t& best_id,
                                                    unsigned long long& n_node, unsigned long long& n_tri) {
     const uint32_t N = s.n_nodes;
-    const V3 o = mk(0.f, 0.f, 0.f);
+    const V3 o = WORLD ? o_in : mk(0.f, 0.f, 0.f);
     const RayRcp rc = ray_rcp(d);
     uint32_t n = valid ? 0u : N;
     best = __builtin_inff(); best_id = -1;
@@ -192,11 +193,17 @@ __device__ __forceinline__ void packet_closest_hit(const DevScene& s, bool valid
             const uint32_t first = (uint32_t)nd.leaf >> LEAF_SHIFT, cnt = (uint32_t)nd.leaf & LEAF_MAX;
             if (__ballot(pass)) {
                 for (uint32_t k = 0; k < cnt; k++) {
-                    const DevTriO tr = s.tris_o[first + k];     // wave-uniform
+                    float t;
+                    if (WORLD) {
+                        const DevTri tr = s.tris[first + k];    // wave-uniform
+                        t = pass ? ray_triangle(o, d, mk(tr.p1x, tr.p1y, tr.p1z), mk(tr.e1x, tr.e1y, tr.e1z), mk(tr.e2x, tr.e2y, tr.e2z)) : SRT_NEG_INF;
+                    } else {
+                        const DevTriO tr = s.tris_o[first + k];     // wave-uniform
+                        t = pass ? ray_triangle_origin(d, mk(tr.tx, tr.ty, tr.tz), mk(tr.e1x, tr.e1y, tr.e1z), mk(tr.e2x, tr.e2y, tr.e2z), mk(tr.qx, tr.qy, tr.qz))
+                                 : SRT_NEG_INF;
+                    }
                     if (pass) {
                         if (COUNT) n_tri++;
-                        const float t = ray_triangle_origin(d, mk(tr.tx, tr.ty, tr.tz), mk(tr.e1x, tr.e1y, tr.e1z), mk(tr.e2x, tr.e2y, tr.e2z),
-                                                            mk(tr.qx, tr.qy, tr.qz));
                         if (t != SRT_NEG_INF && t < best) { best = t; best_id = (int32_t)(first + k); }      // strict '<', ids rise (:429)
                     }
                 }
@@ -238,7 +245,7 @@ __device__ __forceinline__ bool packet_tile_of_wave(const DevParams& p, uint32_t
 // Closest hit, packet form: one wavefront per 8x8 pixel tile.  Writes hit ids, t, the final pixel of a miss, the hit-pixel
 // statistic and (qlist != null) the tile's quadrants with hits into the quadrant list.
 // =================================================================================================
-template <bool COUNT, bool FILTER, bool XCD_ROWS>
+template <bool COUNT, bool FILTER, bool XCD_ROWS, bool WORLD = false>
 __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                         float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                         uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap,
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
     const V3 d = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
     unsigned long long n_node = 0, n_tri = 0;
     float best; int32_t id;
-    packet_closest_hit<COUNT, FILTER>(s, live, d, best, id, n_node, n_tri);
+    packet_closest_hit<COUNT, FILTER, WORLD>(s, live, ray_origin(p), d, best, id, n_node, n_tri);
     const uint32_t tiles_x = (p.W + 7u) / 8u;
     if (live) {
         const size_t pix = (size_t)r * p.W + px;
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, 
             const float t = t_in[pix];
             self = s.obj_range[s.tri_obj[id]];
             so = primary_dir(p, px, image_row(p, r)) * t;                     // :326
+            if (p.cam) so = ray_origin(p) + so;                               // camera mode: the primary ray did not start at 0
         }
         if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
         if (COUNT) diag[4]++;

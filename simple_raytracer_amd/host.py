@@ -53,6 +53,16 @@ def load():
         L.srth_flat_names.restype = C.c_uint32
         L.srth_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _f32p, C.c_int, C.c_int, _f32p]
         L.srth_render.restype = C.c_int64
+        L.srth_renderer_new.argtypes = [C.c_int]
+        L.srth_renderer_new.restype = C.c_void_p
+        L.srth_renderer_free.argtypes = [C.c_void_p]
+        L.srth_renderer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, C.c_int, _f32p]
+        L.srth_renderer_render.restype = C.c_int64
+        L.srth_renderer_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, C.c_int]
+        L.srth_renderer_collect.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _f32p]
+        L.srth_renderer_collect.restype = C.c_int64
+        L.srth_renderer_render_from_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, _f32p, C.c_int, C.c_int, _f32p]
+        L.srth_renderer_render_from_camera.restype = C.c_int64
         L.srth_write_bmp.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u8p]
         L.srth_radians.argtypes = [C.c_float]
         L.srth_radians.restype = C.c_float
@@ -231,6 +241,48 @@ class ObjectManager:
         if n < 0:
             raise HostError(self.L.srth_last_error().decode())
         return rgb, int(n)
+
+
+class Renderer:
+    """srt_host::Renderer: a device scene kept across frames (in-place scene updates, pinned buffers, asynchronous frames, camera mode)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = C.c_void_p(self.L.srth_renderer_new(device))
+        if not self.h:
+            raise HostError("srth_renderer_new failed")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.srth_renderer_free(self.h); self.h = None
+        except Exception:
+            pass
+
+    def _out(self, W, H, want):
+        return np.empty((H, W, 3), np.float32) if want else None
+
+    def _ret(self, n, rgb):
+        if n < 0:
+            raise HostError(self.L.srth_last_error().decode())
+        return (rgb, int(n)) if rgb is not None else int(n)
+
+    def render(self, om, W, H, light4, light_amount=1, image=True):
+        light4 = _f(light4); rgb = self._out(W, H, image)
+        return self._ret(self.L.srth_renderer_render(self.h, om.om, W, H, _p(light4), light_amount, _p(rgb) if image else None), rgb)
+
+    def submit(self, om, W, H, light4, light_amount=1):
+        light4 = _f(light4)
+        _ok(self.L.srth_renderer_submit(self.h, om.om, W, H, _p(light4), light_amount))
+
+    def collect(self, W, H, image=True):
+        rgb = self._out(W, H, image)
+        return self._ret(self.L.srth_renderer_collect(self.h, W, H, _p(rgb) if image else None), rgb)
+
+    def render_from_camera(self, om, W, H, light4_world, view16, light_amount=1, scene_changed=False, image=True):
+        light4_world, view16 = _f(light4_world), _f(view16); rgb = self._out(W, H, image)
+        return self._ret(self.L.srth_renderer_render_from_camera(self.h, om.om, W, H, _p(light4_world), _p(view16), light_amount, int(scene_changed),
+                                                                 _p(rgb) if image else None), rgb)
 
 
 def sort_keys_both_ways(keys):

@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 
 # every symbol include/srt.h declares
-ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy",
-               "srt_render_device", "srt_render", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
+ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy", "srt_scene_update",
+               "srt_render_device", "srt_render", "srt_render_async", "srt_host_alloc", "srt_host_free", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
                "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
                "srt_debug_fail_host_allocs", "srt_scene_pipeline", "srt_scene_overlap_estimate")
 
@@ -51,12 +51,20 @@ def load():
         L.srt_cols_owned.restype = C.c_uint32
         L.srt_scene_create.argtypes = [C.c_int, C.POINTER(abi.SceneDesc), C.POINTER(C.c_void_p)]
         L.srt_scene_create.restype = C.c_int
+        L.srt_scene_update.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc), C.c_void_p]
+        L.srt_scene_update.restype = C.c_int
         L.srt_scene_destroy.argtypes = [C.c_void_p]
         L.srt_scene_destroy.restype = C.c_int
         L.srt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.srt_render_device.restype = C.c_int
         L.srt_render.argtypes = [C.c_void_p, C.POINTER(abi.Params), _i32p, _f32p, _f32p, _u8p, C.POINTER(abi.Stats)]
         L.srt_render.restype = C.c_int
+        L.srt_render_async.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.srt_render_async.restype = C.c_int
+        L.srt_host_alloc.argtypes = [C.c_size_t]
+        L.srt_host_alloc.restype = C.c_void_p
+        L.srt_host_free.argtypes = [C.c_void_p]
+        L.srt_host_free.restype = None
         L.srt_sync.argtypes = [C.c_void_p, C.POINTER(abi.Stats)]
         L.srt_sync.restype = C.c_int
         L.srt_scene_device_bytes.argtypes = [C.c_void_p]
@@ -97,6 +105,12 @@ class DeviceScene:
         d = flat.desc()
         _check(self.L.srt_scene_create(device, C.byref(d), C.byref(h)), "srt_scene_create")
         self.h = h
+
+    def update(self, flat: abi.FlatScene, stream=0):
+        """srt_scene_update: new geometry with the same counts into the existing device allocations (asynchronous on `stream`)."""
+        d = flat.desc()
+        _check(self.L.srt_scene_update(self.h, C.byref(d), C.c_void_p(stream)), "srt_scene_update")
+        self.flat = flat
 
     def close(self):
         if getattr(self, "h", None):

@@ -78,6 +78,27 @@ def _orbit_view(M, radius, angle_deg, height, pitch_deg):
     return M.inverse(view)
 
 
+def orbit_view_matrix(M, radius, angle_deg, height, pitch_deg):
+    """The viewMatrix of main() itself (simple_raytracer.cpp:546-551), whose INVERSE the reference applies to every triangle: what
+    camera mode (srt_params.ray_matrix, an extension) takes as the camera-space -> scene-space ray matrix."""
+    rad = np.float32(M.radians(angle_deg))
+    cx = np.float32(radius) * np.float32(_libm.cosf(float(rad)))
+    cz = np.float32(radius) * np.float32(_libm.sinf(float(rad)))
+    return M.view([cx, height, cz], [M.radians(pitch_deg), M.radians(angle_deg + 90.0), M.radians(0.0)])
+
+
+def in_world_space(recipe, inv):
+    """The same scene script without its last step per object -- the transform into camera space (`inv`, simple_raytracer.cpp:558
+    etc.): the scene where it stands, for camera mode.  The light stays at its world position."""
+    inv16 = [float(np.float32(x)) for x in np.asarray(inv).reshape(16)]
+    r = Recipe()
+    r.ops = [op for op in recipe.ops if not (op[0] == "transform" and op[2] == inv16)]
+    assert len(r.ops) < len(recipe.ops)
+    r.meshes = set(recipe.meshes)
+    r.light = LIGHT_DEFAULT[:3]
+    return r
+
+
 def one_cube(M, angle=0.0):
     """'One Sample Cube for Testing', simple_raytracer.cpp:703-722."""
     r = Recipe(); inv = _orbit_view(M, 100.0, angle, 0.0, 0.0)

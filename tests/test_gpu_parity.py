@@ -143,6 +143,118 @@ def test_tiles_dealt_in_two_dimensions_reassemble_bitwise(srt, name, W, H, L):
         assert np.array_equal(bits(lin.reshape(H, W, 3)), bits(whole["rgb_linear"])) and np.array_equal(bits(t.reshape(H, W)), bits(whole["t"]))
 
 
+@pytest.mark.parametrize("L", [1, 9])
+def test_camera_mode_matches_oracle(srt, oracle, L):
+    """Camera mode (srt_params.ray_matrix; EXTENSION, pinned by the oracle run in the same mode only): the scene of the reference's
+    main() (bunny, three textured trees, ground) left in world space, the hierarchy built once, a different viewMatrix per frame.
+    Hit ids and t bitwise, work counts equal, colours within the tolerance, for several camera angles on ONE device scene."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    exact = scenes.main_scene_no_cats(T, 0.0)
+    world = scenes.in_world_space(exact, scenes._orbit_view(T, 50.0, 0.0, -50.0, 30.0))
+    flat = host.build_flat_scene(world, {k: gu.load_mesh(k) for k in world.meshes})
+    ds = srt.DeviceScene(flat)
+    W, H = 240, 160
+    lights = abi.light_staircase(world.light, L)
+    for angle in (0.0, 70.0, 200.0):
+        view = scenes.orbit_view_matrix(T, 50.0, angle, -50.0, 30.0)
+        p = abi.make_params(W, H, lights, ray_matrix=view, flags=abi.SRT_FLAG_COUNT_WORK)
+        o = ds.render(p); c = oracle.render(flat, p)
+        assert (c["hit_id"] >= 0).sum() > 2000
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), angle
+        assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max()))
+        check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+        for k in ("node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow", "shadow_rays"):
+            assert o["stats"][k] == c["stats"][k], (angle, k)
+        o2 = ds.render(abi.make_params(W, H, lights, ray_matrix=view))       # non-counting build
+        assert np.array_equal(o2["hit_id"], o["hit_id"]) and np.array_equal(bits(o2["rgb_linear"]), bits(o["rgb_linear"]))
+    with pytest.raises(srt.SrtError):
+        ds.render(abi.make_params(W, H, lights, ray_matrix=view, flags=10 << 8))        # only the shipped pipeline takes a camera matrix
+
+
+def test_scene_update_reuses_the_device_scene(srt, oracle):
+    """srt_scene_update: the next frame's geometry (same counts: the reference's builder gives the same tree shape for the same
+    triangle count) into the existing allocations.  Every frame of a small orbit equals the frame of a freshly created scene bit
+    for bit; a scene with other counts is refused, not written half-way."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    meshes = {k: gu.load_mesh(k) for k in ("cube", "bunny")}
+    def frame(angle):
+        r = scenes.Recipe()
+        r.load("bunny", "bunny"); r.color("bunny", (0.9, 0.9, 0.9))
+        r.transform("bunny", T.scaleObj(1500.0, 1500.0, 1500.0)); r.transform("bunny", T.rotateObjX(T.radians(180.0 + angle)))
+        r.transform("bunny", T.changeObjPosition(20.0, 170.0, 300.0)); r.bvh("bunny")
+        r.load("cube", "cube"); r.color("cube", (0.2, 0.7, 0.3))
+        r.transform("cube", T.scaleObj(400.0, 10.0, 400.0)); r.transform("cube", T.changeObjPosition(0.0, 130.0, 350.0)); r.bvh("cube")
+        return host.build_flat_scene(r, meshes)
+    W, H, L = 192, 108, 2
+    lights = abi.light_staircase((300.0, -600.0, -100.0), L)
+    p = abi.make_params(W, H, lights)
+    f0 = frame(0.0)
+    ds = srt.DeviceScene(f0)
+    first = ds.render(p)
+    for angle in (7.0, 31.0, 0.0):
+        f = frame(angle)
+        ds.update(f)
+        o = ds.render(p)
+        fresh = srt.DeviceScene(f).render(p)
+        assert np.array_equal(o["hit_id"], fresh["hit_id"]) and np.array_equal(bits(o["t"]), bits(fresh["t"]))
+        assert np.array_equal(bits(o["rgb_linear"]), bits(fresh["rgb_linear"])) and np.array_equal(o["rgb8"], fresh["rgb8"])
+        c = oracle.render(f, p)
+        assert np.array_equal(o["hit_id"], c["hit_id"])
+    assert np.array_equal(o["hit_id"], first["hit_id"]) and not np.array_equal(ds.render(p)["hit_id"], srt.DeviceScene(frame(7.0)).render(p)["hit_id"])
+    g, _ = device_scene(srt, "cube")
+    with pytest.raises(srt.SrtError) as e:
+        ds.update(g.flat)                      # other counts
+    assert e.value.code == abi.SRT_ERR_LAYOUT
+    assert np.array_equal(ds.render(p)["hit_id"], first["hit_id"])        # the refused update changed nothing
+
+
+def test_renderer_keeps_the_scene_across_frames(srt, oracle):
+    """srt_host::Renderer (what the drop-in sendRaysAndIntersectPointsColors runs on): a small orbit through render(), through
+    submit() / collect() with the next frame built in between, and through camera mode; every frame against the oracle."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    cube = gu.load_mesh("cube")
+    W, H = 160, 120
+    r = host.Renderer(0)
+    def exact_frame(angle):
+        rec = scenes.four_cubes(T, angle)
+        om = host.ObjectManager(); rec.replay(om, {"cube": cube})
+        return rec, om
+    def expect(flat, light, **kw):
+        p = abi.make_params(W, H, abi.light_staircase(light, 2), **kw)
+        p.background[0] = p.background[1] = p.background[2] = 0
+        return oracle.render(flat, p)["rgb8"].astype(np.float32)
+    rec, om = exact_frame(0.0)
+    for k, angle in enumerate((0.0, 10.0, 20.0, 30.0)):
+        if k % 2 == 0:
+            img, n = r.render(om, W, H, list(rec.light) + [1.0], light_amount=2)
+            nxt = exact_frame(angle + 10.0)
+        else:
+            r.submit(om, W, H, list(rec.light) + [1.0], light_amount=2)
+            nxt = exact_frame(angle + 10.0)                # host work while the frame is in flight
+            img, n = r.collect(W, H)
+        want = expect(om.flatten(), rec.light)
+        d = np.abs(img - want)
+        assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2 and n > 1500, angle
+        rec, om = nxt
+    # camera mode: world-space scene uploaded once, a viewMatrix per frame
+    world = scenes.in_world_space(scenes.four_cubes(T, 0.0), scenes._orbit_view(T, 100.0, 0.0, 0.0, 0.0))
+    omw = host.ObjectManager(); world.replay(omw, {"cube": cube})
+    flat_w = omw.flatten()
+    rc = host.Renderer(0)
+    for k, angle in enumerate((0.0, 15.0, 140.0)):
+        view = scenes.orbit_view_matrix(T, 100.0, angle, 0.0, 0.0)
+        img, n = rc.render_from_camera(omw, W, H, list(world.light) + [1.0], view, light_amount=2, scene_changed=(k == 0))
+        want = expect(flat_w, world.light, ray_matrix=view)
+        d = np.abs(img - want)
+        assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2 and n > 1500, angle
+
+
 def test_soup_scene_matches_oracle(srt, oracle):
     """Synthetic triangle soup (BASELINE config 5 generator) at a size the oracle finishes in seconds:
     4 objects, cross-object shadows, built by the oracle-side reference-free path."""

@@ -297,3 +297,30 @@ def test_integration_adapter_compiles_against_the_reference(tmp_path):
            "-I" + os.path.join(root, "include"), str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_camera_mode_definition_against_the_exact_frame(oracle):
+    """Camera mode (srt_params.ray_matrix, an EXTENSION: the reference always moves the scene, never the camera): the scene of
+    main()'s 4-cube script left in world space, rays taken there by the viewMatrix, must show what the reference's frame shows --
+    same geometry, different rounding and a different hierarchy (built from world-space keys), so the comparison is geometric:
+    t to 1e-4 relative and the 8-bit image within 2 LSB on all but a sliver of silhouette pixels."""
+    import scenes
+    from simple_raytracer_amd import abi, host
+    T = host.Transformation
+    cube = gu.load_mesh("cube")
+    for angle in (0.0, 40.0):
+        exact = scenes.four_cubes(T, angle)
+        inv = scenes._orbit_view(T, 100.0, angle, 0.0, 0.0)
+        view = scenes.orbit_view_matrix(T, 100.0, angle, 0.0, 0.0)
+        world = scenes.in_world_space(exact, inv)
+        f_exact = host.build_flat_scene(exact, {"cube": cube})
+        f_world = host.build_flat_scene(world, {"cube": cube})
+        W, H, L = 160, 120, 3
+        a = oracle.render(f_exact, abi.make_params(W, H, abi.light_staircase(exact.light, L)))
+        b = oracle.render(f_world, abi.make_params(W, H, abi.light_staircase(world.light, L), ray_matrix=view))
+        hit_a, hit_b = a["hit_id"] >= 0, b["hit_id"] >= 0
+        assert (hit_a != hit_b).mean() < 2e-3 and hit_a.sum() > 2000
+        both = hit_a & hit_b
+        assert np.abs(a["t"][both] - b["t"][both]).max() < 1e-4 * a["t"][both].max()
+        d8 = np.abs(a["rgb8"].astype(int) - b["rgb8"].astype(int)).max(-1)
+        assert (d8[both] > 2).mean() < 5e-3
