@@ -469,6 +469,10 @@ def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
     insts = c["SQ_INSTS_VALU"]
     lanes = (c.get("SQ_THREAD_CYCLES_VALU", 0.0) / insts) if insts else 0.0
     issue = insts * 4.0 / (1024.0 * cycles) if cycles else 0.0
+    issue_note = None
+    if issue > 1.0:      # measured on the packet closest-hit kernel: 1.11.  Some VALU instructions of a wave64 issue in fewer than 4 cycles, so
+        issue_note = f"wave-instructions x 4 / SIMD-cycles = {issue:.3f} > 1: the 4-cycles-per-instruction yardstick is exceeded, i.e. the VALUs are saturated; capped at 1"
+        issue = 1.0
     valu_frac = issue * lanes / 64.0
     traffic = pmc.get("traffic_bytes")
     if traffic is None:
@@ -478,7 +482,7 @@ def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
     common = {"kernel": kernel, "kernel_ms": round(kernel_ms, 5), "kernel_ms_under_profiler": round(prof_ms, 5), "traffic": int(traffic),
               "hbm_GBps": round(hbm_gbs, 1), "hbm_frac": round(hbm_frac, 4),
               "valu": {"wave_insts_per_launch": int(insts), "launch_cycles": int(cycles), "clock_GHz": round(clock_ghz, 3), "issue_frac": round(issue, 4),
-                       "lanes_active_of_64": round(lanes, 1), "frac_of_lane_peak": round(valu_frac, 4)},
+                       "lanes_active_of_64": round(lanes, 1), "frac_of_lane_peak": round(valu_frac, 4), **({"note": issue_note} if issue_note else {})},
               "source": pmc["source"], **eff}
     if hbm_frac >= 0.25 and hbm_frac >= valu_frac:
         return {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), **common}

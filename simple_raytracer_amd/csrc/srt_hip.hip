@@ -694,6 +694,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             } else if (fused) {        // closest hit + shadow rays in one launch
                 if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (variant == 12) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // round-1 form: roots re-tested per wave (A/B)
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);

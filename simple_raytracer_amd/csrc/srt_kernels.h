@@ -343,7 +343,9 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                                                   unsigned long long* __restrict__ counters, int32_t& out_id, float& out_t, V3& out_d,
                                                   const uint32_t bx, const uint32_t by, const uint32_t gx,      // workgroup tile coordinates, tiles per row
                                                   const uint32_t wave,                                          // quadrant of the tile this wave owns
-                                                  uint32_t* __restrict__ qcount = nullptr, uint32_t* __restrict__ qlist = nullptr, uint32_t qcap = 0) {   // list of quadrants with hits (4x4 waves only)
+                                                  uint32_t* __restrict__ qcount = nullptr, uint32_t* __restrict__ qlist = nullptr, uint32_t qcap = 0,   // list of quadrants with hits (4x4 waves only)
+                                                  const uint32_t* root_pass = nullptr) {      // per ray of this quadrant: which objects' ROOT boxes it passes (bit = object), from
+                                                                                              // finish_background_tile, which has put all 64 rays of the tile through every root already
     constexpr int P = 1 << (TWL + THL);           // rays per wavefront
     const uint32_t lane = threadIdx.x & 63;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
@@ -434,6 +436,26 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     for (uint32_t obj0 = 0; obj0 < n_obj && nlive; obj0 += OBJ_G) {
         // roots of up to OBJ_G objects for every live pixel, in chunks of 64 (node, pixel) pairs
         const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
+        if (!COUNT && root_pass) {
+            // the root tests are done (wave 0 ran them for the whole tile with full lanes): queue what a passing root queues -- its two
+            // children, or its triangles -- and skip the first node step, which would run at 16 rays x 2 roots = 32 of 64 lanes
+            for (uint32_t base = 0; base < P * g; base += 64) {
+                const uint32_t k = base + lane;
+                const uint32_t pl = k & (P - 1), ob = k >> (TWL + THL);
+                const bool ok = k < P * g && ((livem >> pl) & 1ull) && ((root_pass[pl] >> (obj0 + ob)) & 1u);
+                int32_t root = 0, info = -1;
+                if (ok) { root = s.obj_range[obj0 + ob].x; info = s.nodes[root].leaf; }
+                const bool inner = ok && info < 0, leafp = ok && info >= 0 && (info & LEAF_MAX) != 0;
+                const unsigned long long im = __ballot(inner);
+                if (inner) {
+                    const uint32_t pos = nqn + 2 * lane_prefix(im);
+                    nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
+                    nq[pos + 1] = ((uint32_t)(root + 1) << 6) | pl;   // left child on top: popped first
+                }
+                nqn += 2 * (uint32_t)__popcll(im);
+                push_tris((uint32_t)info, leafp, pl);
+            }
+        } else
         for (uint32_t base = 0; base < P * g; base += 64) {
             const uint32_t k = base + lane;
             const uint32_t pl = k & (P - 1), ob = k >> (TWL + THL);
@@ -586,7 +608,8 @@ template <bool FILTER>
 __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                        float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                        unsigned long long* __restrict__ shadow_bits,
-                                                       const uint32_t bx, const uint32_t by, const uint32_t gx) {
+                                                       const uint32_t bx, const uint32_t by, const uint32_t gx,
+                                                       uint32_t* root_pass = nullptr) {      // LDS, 64 words (quadrant * 16 + pixel): out, per ray the objects whose root box it passes
     __shared__ uint32_t tile_live;
     if ((threadIdx.x >> 6) == 0) {
         const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
@@ -597,6 +620,7 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
         const RayRcp rc = ray_rcp(dd);
         const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
         bool any = false;
+        uint32_t pmask = 0;
         for (uint32_t ob = 0; ob < s.n_objects; ob++) {
             const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
             const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
@@ -607,7 +631,9 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
                 if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
             } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
             any |= pass;
+            if (pass && ob < 32u) pmask |= 1u << ob;
         }
+        if (root_pass) root_pass[lane] = live ? pmask : 0u;
         const unsigned long long m = __ballot(live && any);
         if (lane == 0) tile_live = m != 0ull;
         if (m == 0ull) {
@@ -640,9 +666,12 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ float4 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
-    if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x)) return;
+    __shared__ uint32_t root_pass[64];
+    const bool roots_done = !COUNT && TWL == 2 && THL == 2 && s.n_objects <= 32u;      // wave 0 tests every root for the tile's 64 rays first
+    if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
     closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave, qcount, qlist, qcap);
+                                                      hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave, qcount, qlist, qcap,
+                                                      roots_done ? root_pass + wave * 16 : nullptr);
 }
 
 // =================================================================================================
@@ -1003,7 +1032,8 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
 // tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
 // a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
 // =================================================================================================
-template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false>
+// ROOTS_AGAIN: the round-1 form (every wave re-tests the roots), for A/B
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
@@ -1028,9 +1058,12 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p,
         by = (idx / gx) * 8u + (w & 7u); bx = idx % gx;
         if (by >= (p.rows + 7u) / 8u) return;
     }
-    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx)) return;
+    __shared__ uint32_t root_pass[64];
+    const bool roots_done = !COUNT && !ROOTS_AGAIN && s.n_objects <= 32u;              // wave 0 tests every root for the tile's 64 rays first
+    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave);
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
+                                                  roots_done ? root_pass + wave * 16 : nullptr);
     __builtin_amdgcn_wave_barrier();
     shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
 #ifdef SRT_DIAG

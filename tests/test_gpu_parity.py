@@ -294,6 +294,35 @@ def test_deep_soup_rows_match_oracle(srt, oracle):
         assert np.array_equal(o2["hit_id"], c["hit_id"]) and np.array_equal(bits(o2["rgb_linear"]), bits(o["rgb_linear"]))
 
 
+def test_k5_soup_at_full_size_band(srt, oracle):
+    """BASELINE configs[4] at its own size: 1,000,000 random triangles (4 objects, depth-15 trees), a 4096-wide frame, supersampled
+    (spp = 4, the extension) -- a band of scanlines through the pipeline the library picks by itself for such a scene (packet closest
+    hit, whole tile rows per XCD because the records are far beyond an L2, node-queue shadow rays), against the oracle: hit ids and
+    t bitwise, colours within the tolerance, the counting build's work counts."""
+    import scenes
+    from simple_raytracer_amd import host
+    recipe, meshes = scenes.soup(1000000)
+    flat = host.build_flat_scene(recipe, meshes)
+    assert flat.n_tris == 1000000 and flat.n_nodes > 250000
+    ds = srt.DeviceScene(flat)
+    assert ds.overlap_estimate > 150 and ds.device_bytes > (32 << 20)
+    W = H = 4096
+    kw = dict(block_rows=8, block_first=2048 // 8, block_stride=10 ** 6, spp=4)
+    lights = abi.light_staircase(recipe.light, 1)
+    p = abi.make_params(W, H, lights, **kw)
+    o = ds.render(p)
+    assert ds.pipeline == "k_closest_hit_pk+k_shadow_nq+k_shade_tile"
+    c = oracle.render(flat, p)
+    assert o["hit_id"].shape == (8, W) and (c["hit_id"] >= 0).mean() > 0.3
+    assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+    oc = ds.render(abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK, **kw))
+    for k in ("primary_rays", "hit_rays", "shadow_rays", "node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow"):
+        assert oc["stats"][k] == c["stats"][k], k
+    assert c["stats"]["node_tests_primary"] / c["stats"]["primary_rays"] > 300       # hundreds of slab tests per ray: the boxes overlap heavily
+
+
 @pytest.mark.parametrize("name,W,H,L,spp", [("cubes4_a0", 128, 96, 3, 4), ("ground_bunny", 96, 54, 1, 9), ("texquad", 64, 48, 2, 16), ("cubes4_a0", 96, 64, 9, 4)])
 def test_supersampling_extension_matches_oracle(srt, oracle, name, W, H, L, spp):
     """spp > 1 does not exist in the reference: pinned by the oracle's restatement of the same
