@@ -599,7 +599,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool count = (p->flags & SRT_FLAG_COUNT_WORK) != 0;
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
-    if (force_nq || variant == 25) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    const bool coarse_grid = variant == 27;                // 27: variant 0 with 2 x 2 tiles per workgroup in the unfused closest-hit launch (A/B, not shipped)
+    if (force_nq || variant == 25 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -664,9 +665,10 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         //                scene), 1..7 light samples, or variant 23
         //   pk + pk      both packet kernels: such scenes with 8+ light samples, or variant 22
         //   nq chunked   the round-1 form for 8+ samples (k_shadow_nq, 64 rays in flight, samples cut over blockIdx.z): variant 20
-        // camera mode (rays that do not start at the origin) runs on the packet kernels, which take a general ray
+        // camera mode (rays that do not start at the origin): closest hit on the packet kernel, which takes a general ray; the shadow
+        // kernels start from the hit point either way
         const bool pk_closest = fp.cam || variant == 22 || variant == 23 || (variant == 0 && s->prefer_packet && !force_nq);
-        const bool pk_shadow = p->n_lights && (fp.cam || variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
+        const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
@@ -698,6 +700,12 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+            } else if (!count && coarse_grid) {
+                // 2 x 2 tiles per workgroup (a quarter of the workgroups for frames that are mostly background).  Measured and NOT
+                // shipped: K4 closest hit 0.44 ms against 0.29 with one tile per workgroup, K3 0.22 against 0.10 -- the launch is not
+                // dispatch-bound, and a workgroup that walks its live tiles one after the other is a longer tail
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, true>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream,
+                                   s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }

@@ -604,6 +604,53 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
 // other three waves wait at a launch-time barrier (nobody has work to wait behind yet); if no ray passes any root it writes
 // the 64 background pixels (and, when shadow_bits is given, the tile's all-clear shadow words) with full lanes.  Returns true
 // to every thread of the workgroup when the tile is finished.
+// One WAVE puts the 64 rays of tile (bx, by) through every object's root box; if none passes any it writes the tile's background
+// pixels (and all-clear shadow words).  Returns (wave-uniform) whether the tile is live; root_pass (LDS, 64 words, quadrant * 16 +
+// pixel) receives, per ray, the objects whose root box it passes.
+template <bool FILTER>
+__device__ __forceinline__ bool background_test_wave(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                     unsigned long long* __restrict__ shadow_bits,
+                                                     const uint32_t bx, const uint32_t by, const uint32_t gx, uint32_t* root_pass) {
+    const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
+    const uint32_t px = bx * 8 + (quad & 1) * 4 + (ql & 3), r = by * 8 + (quad >> 1) * 4 + (ql >> 2);
+    const bool live = pixel_live(p, px, r);
+    const V3 o = mk(0.f, 0.f, 0.f);
+    const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
+    const RayRcp rc = ray_rcp(dd);
+    const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
+    bool any = false;
+    uint32_t pmask = 0;
+    for (uint32_t ob = 0; ob < s.n_objects; ob++) {
+        const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
+        const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+        bool pass;
+        if (FILTER) {
+            bool amb;
+            pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
+            if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+        } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
+        any |= pass;
+        if (pass && ob < 32u) pmask |= 1u << ob;
+    }
+    if (root_pass) root_pass[lane] = live ? pmask : 0u;
+    const unsigned long long m = __ballot(live && any);
+    if (m == 0ull) {
+        if (live) {      // what closest_hit_phase writes for a miss (:518, drawImage:476-487)
+            const size_t pix = (size_t)r * p.W + px;
+            hit_id[pix] = -1;
+            t_out[pix] = __builtin_inff();
+            if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
+            if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
+        }
+        if (shadow_bits) {
+            const size_t tile_index = (size_t)by * gx + bx;
+            for (uint32_t l = lane; l < p.n_lights; l += 64) shadow_bits[tile_index * p.n_lights + l] = 0ull;
+        }
+    }
+    return m != 0ull;
+}
+
 template <bool FILTER>
 __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                        float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
@@ -612,49 +659,18 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
                                                        uint32_t* root_pass = nullptr) {      // LDS, 64 words (quadrant * 16 + pixel): out, per ray the objects whose root box it passes
     __shared__ uint32_t tile_live;
     if ((threadIdx.x >> 6) == 0) {
-        const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
-        const uint32_t px = bx * 8 + (quad & 1) * 4 + (ql & 3), r = by * 8 + (quad >> 1) * 4 + (ql >> 2);
-        const bool live = pixel_live(p, px, r);
-        const V3 o = mk(0.f, 0.f, 0.f);
-        const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
-        const RayRcp rc = ray_rcp(dd);
-        const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
-        bool any = false;
-        uint32_t pmask = 0;
-        for (uint32_t ob = 0; ob < s.n_objects; ob++) {
-            const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
-            const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
-            bool pass;
-            if (FILTER) {
-                bool amb;
-                pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
-                if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-            } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-            any |= pass;
-            if (pass && ob < 32u) pmask |= 1u << ob;
-        }
-        if (root_pass) root_pass[lane] = live ? pmask : 0u;
-        const unsigned long long m = __ballot(live && any);
-        if (lane == 0) tile_live = m != 0ull;
-        if (m == 0ull) {
-            if (live) {      // what closest_hit_phase writes for a miss (:518, drawImage:476-487)
-                const size_t pix = (size_t)r * p.W + px;
-                hit_id[pix] = -1;
-                t_out[pix] = __builtin_inff();
-                if (rgb_linear) { rgb_linear[pix * 3] = 0.0f; rgb_linear[pix * 3 + 1] = 0.0f; rgb_linear[pix * 3 + 2] = 0.0f; }
-                if (rgb8) { rgb8[pix * 3] = (uint8_t)(p.bg & 255); rgb8[pix * 3 + 1] = (uint8_t)((p.bg >> 8) & 255); rgb8[pix * 3 + 2] = (uint8_t)((p.bg >> 16) & 255); }
-            }
-            if (shadow_bits) {
-                const size_t tile_index = (size_t)by * gx + bx;
-                for (uint32_t l = lane; l < p.n_lights; l += 64) shadow_bits[tile_index * p.n_lights + l] = 0ull;
-            }
-        }
+        const bool live = background_test_wave<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass);
+        if ((threadIdx.x & 63) == 0) tile_live = live ? 1u : 0u;
     }
     __syncthreads();
     return tile_live == 0u;
 }
 
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
+// COARSE: a workgroup owns 2 x 2 tiles (16 x 16 pixels): its four waves put one tile's 64 rays each through the root boxes at once,
+// then work through the live tiles one after the other (four waves per tile, as ever).  For frames that are mostly background
+// (3840x2160 of the reference's scenes: 94 % of 129,600 tiles) the launch is bound by workgroup dispatch, and this is a quarter
+// of the workgroups; the host picks it for big frames only (a frame full of geometry keeps the finer grid's balance).
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false>
 __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
                                                         uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
@@ -666,6 +682,27 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ float4 dir_all[4][P];
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
+    if (COARSE && !COUNT && TWL == 2 && THL == 2) {
+        __shared__ uint32_t root_pass4[4][64];
+        __shared__ uint32_t live4[4];
+        const uint32_t gx = (p.W + 7u) / 8u, gy = (p.rows + 7u) / 8u;
+        {
+            const uint32_t bx = blockIdx.x * 2u + (wave & 1u), by = blockIdx.y * 2u + (wave >> 1);
+            bool live = false;
+            if (bx < gx && by < gy) live = background_test_wave<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, bx, by, gx, root_pass4[wave]);
+            if ((threadIdx.x & 63) == 0) live4[wave] = live ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool roots_done = s.n_objects <= 32u;
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (!live4[k]) continue;                                  // workgroup-uniform
+            closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                              hit_id, t_out, rgb_linear, rgb8, counters, id, t, d,
+                                                              blockIdx.x * 2u + (k & 1u), blockIdx.y * 2u + (k >> 1), gx, wave, qcount, qlist, qcap,
+                                                              roots_done ? root_pass4[k] + wave * 16 : nullptr);
+        }
+        return;
+    }
     __shared__ uint32_t root_pass[64];
     const bool roots_done = !COUNT && TWL == 2 && THL == 2 && s.n_objects <= 32u;      // wave 0 tests every root for the tile's 64 rays first
     if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
@@ -799,7 +836,7 @@ template <int RS>                  // RS = shadow rays in flight per round: 16, 
 struct ShadowLds {
     float4 ray[2 * RS];            // per ray slot: origin, direction
     float4 pixd[NQ_P];             // per hit rank: t, pixel lane, own object's node range
-    float2 pdir[NQ_P];             // per hit rank: primary ray direction x, y
+    float4 pso[NQ_P];              // per hit rank: the shadow rays' origin d * t (:326)
     int2 selfr[RS];                // per ray slot: node range of the hit object
     uint32_t flag[RS];
     uint32_t mask[64];             // per light sample of the current group: shadowed pixels of this wave's 4x4 quadrant
@@ -835,7 +872,9 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         const int2 self = s.obj_range[s.tri_obj[id]];
         const uint32_t rank = __popc(hm & ((1u << lane) - 1u));
         pixd[rank] = make_float4(t_hit, __uint_as_float(lane), __int_as_float(self.x), __int_as_float(self.y));
-        L.pdir[rank] = make_float2(d_hit.x, d_hit.y);
+        V3 so_px = d_hit * t_hit;                                      // :326
+        if (p.cam) so_px = ray_origin(p) + so_px;                      // camera mode: the primary ray did not start at 0
+        L.pso[rank] = make_float4(so_px.x, so_px.y, so_px.z, 0.f);
     }
     uint32_t nqn = 0, tqn = 0;
 
@@ -896,11 +935,10 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                 const float4 pd = pixd[hr];
                 pl = __float_as_uint(pd.y);
                 self = make_int2(__float_as_int(pd.z), __float_as_int(pd.w));
-                const float2 dxy = L.pdir[hr];
-                const V3 d = mk(dxy.x, dxy.y, p.focal);
+                const float4 so4 = L.pso[hr];
                 const uint32_t l = l0 + lg;
                 const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-                so = d * pd.x;                                    // :326
+                so = mk(so4.x, so4.y, so4.z);
                 sd = L - so;                                      // :325
             }
             bool shadowed = false;
@@ -1133,9 +1171,14 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
     const uint32_t n_lch = (p.n_lights + 63u) >> 6;
     const unsigned long long* sb = p.shadow_px_major ? shadow_bits + pix * n_lch : shadow_bits + tile_index * p.n_lights;
     const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
+    unsigned long long word = 0ull;                        // pixel-major: the pixel's shadow bits of the current 64 samples, loaded once per 64
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-        const bool shadowed = p.shadow_px_major ? ((sb[l >> 6] >> (l & 63u)) & 1ull) : ((sb[l] >> sbit) & 1ull);
+        bool shadowed;
+        if (p.shadow_px_major) {
+            if ((l & 63u) == 0u) word = sb[l >> 6];
+            shadowed = (word >> (l & 63u)) & 1ull;
+        } else shadowed = (sb[l] >> sbit) & 1ull;
         V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
         if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
         sum = sum + c;                                                                          // :370
