@@ -62,9 +62,14 @@ class FrameGather:
         if rank == dst:
             self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(slots)] if world > 1 else None
             self.frame = torch.empty((self.frames_total, height, width, channels), dtype=dtype, device=device)
-            # sender r: positions of its real pixels inside the padded [max_rows, max_cols] tile, and where they go in the frame
+            # sender r: positions of its real pixels inside the padded [max_rows, max_cols] tile, and where they go in the frame.
+            # Whole-width blocks move as whole rows (one contiguous W x C run each); tiles dealt in two dimensions pixel by pixel.
             self.src, self.index = [], []
             for pm in self.pix_of:
+                if not self.block_cols:
+                    self.src.append(None)
+                    self.index.append(torch.as_tensor(pm[:, 0] // width, dtype=torch.long, device=device))      # image row of each local row
+                    continue
                 pos = (np.arange(pm.shape[0], dtype=np.int64)[:, None] * self.max_cols + np.arange(pm.shape[1], dtype=np.int64)[None, :])[pm >= 0]
                 self.src.append(torch.as_tensor(pos, dtype=torch.long, device=device))
                 self.index.append(torch.as_tensor(pm[pm >= 0], dtype=torch.long, device=device))
@@ -102,8 +107,11 @@ class FrameGather:
         for r in range(self.world):
             if self.index[r].numel():       # sender r holds its pixels of the frames of its group: frames group, group + F, ...
                 mine = self.frame[r // self.per_group :: self.groups]
-                flat = self.recv[k][r].reshape(mine.shape[0], -1, C).index_select(1, self.src[r])
-                mine.view(mine.shape[0], -1, C).index_copy_(1, self.index[r], flat)
+                if self.src[r] is None:     # whole rows
+                    mine.index_copy_(1, self.index[r], self.recv[k][r][:, : self.index[r].numel()])
+                else:
+                    flat = self.recv[k][r].reshape(mine.shape[0], -1, C).index_select(1, self.src[r])
+                    mine.view(mine.shape[0], -1, C).index_copy_(1, self.index[r], flat)
         return self.frame
 
     def finish_all(self):
