@@ -212,6 +212,59 @@ def test_scene_update_reuses_the_device_scene(srt, oracle):
     assert np.array_equal(ds.render(p)["hit_id"], first["hit_id"])        # the refused update changed nothing
 
 
+def test_textured_asset_from_files_through_the_loader_to_hip(srt, oracle, tmp_path):
+    """Loader -> HIP with a TEXTURED asset read from files on the GPU box (the reference's assets do not travel): the tree mesh of
+    the committed fixture is written out as OBJ + MTL + PNG (texture coordinates chosen so that the loader's floor(tx * W) mod W /
+    floor((1 - ty) * H) mod H, Object.cpp:113-119, give back the fixture's integer texel coordinates), loaded by the host mirror's
+    own OBJ / MTL / PNG reader, and rendered; the image must be the one the same mesh gives when it is fed from the arrays (whose
+    equality with the reference's loader output is what tests/test_host_mirror.py pins in the build container)."""
+    from PIL import Image
+    import scenes
+    from simple_raytracer_amd import host
+    m = gu.load_mesh("tree")
+    pts, tc, tex = m["points"], m["texcoord"], m["texture"]
+    n = 6000                                                    # a slice of the 36,000 triangles keeps the OBJ small
+    pts, tc = pts[:n], tc[:n]
+    Ht, Wt = tex.shape[:2]
+    Image.fromarray(tex).save(tmp_path / "bark.png")
+    (tmp_path / "t.mtl").write_text(f"newmtl m\nKd 1 1 1\nmap_Kd {tmp_path}/bark.png\n")
+    lines = ["mtllib t.mtl", "usemtl m"]
+    for tri in pts:
+        for v in tri:
+            lines.append("v %.9g %.9g %.9g" % (float(v[0]), float(v[1]), float(v[2])))
+    for t6 in tc:
+        for k in range(3):
+            lines.append("vt %.9f %.9f" % ((float(t6[2 * k]) + 0.5) / Wt, 1.0 - (float(t6[2 * k + 1]) + 0.5) / Ht))
+    for i in range(n):
+        a = 3 * i + 1
+        lines.append(f"f {a}/{a} {a + 1}/{a + 1} {a + 2}/{a + 2}")
+    obj = tmp_path / "t.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    T = host.Transformation
+    def script(om, name):
+        om.transformTriangles(name, T.scaleObj(0.1, 0.1, 0.1)); om.transformTriangles(name, T.rotateObjX(T.radians(-90.0)))
+        om.transformTriangles(name, T.changeObjPosition(0.0, 20.0, 120.0)); om.createBoundingHierarchy(name)
+    cube = gu.load_mesh("cube")
+    def ground(om):         # an untextured slab under the tree: cross-object shadows on both
+        om.add_object("ground", cube); om.setColor("ground", (0.3, 0.6, 0.3))
+        om.transformTriangles("ground", T.scaleObj(60.0, 2.0, 60.0)); om.transformTriangles("ground", T.changeObjPosition(0.0, 23.0, 125.0))
+        om.createBoundingHierarchy("ground")
+    a = host.ObjectManager(); a.loadObjFile(str(obj)); script(a, str(obj)); ground(a)
+    b = host.ObjectManager(); b.add_textured_object(str(obj), pts, tc, str(tmp_path / "bark.png"), tex); script(b, str(obj)); ground(b)
+    fa, fb = a.flatten(), b.flatten()
+    assert fa.n_tris == n + 12 and fa.n_textures == 1 and fa.names == fb.names
+    assert np.array_equal(fa.tri_points, fb.tri_points) and np.array_equal(fa.tri_texcoord, fb.tri_texcoord) and np.array_equal(fa.tex_rgb, fb.tex_rgb)
+    W, H, L = 200, 150, 2
+    light = (120.0, -260.0, -40.0)
+    p = abi.make_params(W, H, abi.light_staircase(light, L))
+    o = srt.DeviceScene(fa).render(p)
+    c = oracle.render(fb, p)
+    assert (c["hit_id"] >= 0).sum() > 1500 and len(np.unique(c["rgb8"].reshape(-1, 3), axis=0)) > 200     # textured, not flat
+    assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
+
+
 def test_renderer_keeps_the_scene_across_frames(srt, oracle):
     """srt_host::Renderer (what the drop-in sendRaysAndIntersectPointsColors runs on): a small orbit through render(), through
     submit() / collect() with the next frame built in between, and through camera mode; every frame against the oracle."""
