@@ -729,7 +729,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);      // 80 VGPRs: six waves per SIMD (86 without the bound: five)
             HIP_TRY(hipGetLastError());
         }
         if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
