@@ -53,9 +53,13 @@ def parse_args():
                                                        "(BASELINE.json configs[4] names 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams the frames of a step are spread over (each with its own scene handle and buffers).  Default: 1 "
-                         "at N = 1 (kernels run alone, so their durations are the ones rocprofv3 reports), 4 at N > 1, where a rank's "
-                         "share of a frame is too small to fill the chip and independent frames overlap their ramp-up and tails")
+                    help="HIP streams the frames of a step are spread over (each with its own scene handle and buffers, one copy of the scene's "
+                         "records).  Default 4: one frame's shading overlaps the next frame's tracing.  The per-kernel durations of the "
+                         "roofline block are measured on eager launches on ONE stream either way; profile with --streams 1 to see kernels alone")
+    ap.add_argument("--batch-groups", type=int, default=1, help="with --batch: the batches of a step go to this many streams in turn")
+    ap.add_argument("--batch-frames", type=int, default=0, help="with --batch: frames per srt_render_device_batch call (0 = as many as keep the intermediates in cache)")
+    ap.add_argument("--batch", choices=["auto", "on", "off"], default="auto",
+                    help="the frames of a step through srt_render_device_batch (one pair of launches); auto = when this rank owns a share of each frame")
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 logic on a box with fewer "
@@ -128,8 +132,20 @@ def measure(args):
         g = soup_workload(args.tris)
     else:
         g = gu.GoldenScene(args.workload)
-    S = max(1, min(args.streams if args.streams > 0 else (1 if (world == 1 and not args.emulate_split) else 4), B))
-    scenes_ = [lib.DeviceScene(g.flat, device=local_rank) for _ in range(S)]     # one handle (workspace, counters) per stream
+    # Frames of a step go to S streams in turn (one scene handle each: own workspace, ONE copy of the records, srt_scene_share): one
+    # frame's shading -- a short, latency-bound launch -- overlaps the next frame's tracing.  K3, N = 1: 0.147 ms per frame on one
+    # stream, 0.137 on two, 0.135 on four.
+    S = max(1, min(args.streams if args.streams > 0 else 4, B))
+    # A rank that owns an EIGHTH of every frame (or less) issues the frames of a step through srt_render_device_batch (fused
+    # pipeline, 1..7 light samples): one pair of launches for all of them, which fills the chip where such a share does not
+    # (0.0203 ms per share against 0.0256 frame by frame on 4 streams).  Bigger shares fill it well enough, and frame by
+    # frame their shading overlaps the next trace (a half: 0.0707 against 0.0768 batched; whole frames 0.135 against 0.149).
+    # One handle per frame of a batch, else one per stream.
+    split_n = int(args.emulate_split.split("/")[1]) if args.emulate_split else world // max(1, args.frame_groups)
+    n_mine = B // max(1, args.frame_groups)
+    batch = (args.batch == "on" or (args.batch == "auto" and split_n > 4)) and 1 <= L <= 7 and args.variant == 0 and args.spp == 1 and n_mine > 1
+    scenes_ = [lib.DeviceScene(g.flat, device=local_rank)]
+    scenes_ += [scenes_[0].share() for _ in range((max(S, n_mine) if batch else S) - 1)]      # the frames of a step render ONE scene: one copy of its records
     scene = scenes_[0]
     lights = abi.light_staircase(g.light, L)
     from simple_raytracer_amd import tiling
@@ -145,9 +161,10 @@ def measure(args):
     p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=args.variant << 8, spp=args.spp)
     rows, Wl = scene.rows(p), scene.cols(p)
     dev = torch.device("cuda", local_rank)
-    hit = torch.empty((S, rows, Wl), dtype=torch.int32, device=dev)
-    tbuf = torch.empty((S, rows, Wl), dtype=torch.float32, device=dev)
-    lin = torch.empty((S, rows, Wl, 3), dtype=torch.float32, device=dev)
+    NB = len(scenes_)
+    hit = torch.empty((NB, rows, Wl), dtype=torch.int32, device=dev)
+    tbuf = torch.empty((NB, rows, Wl), dtype=torch.float32, device=dev)
+    lin = torch.empty((NB, rows, Wl, 3), dtype=torch.float32, device=dev)
     side = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
     # the 8-bit framebuffer tiles of the B frames of a step live in the gather object (padded to equal rows
     # on every rank) so that the kernels write straight into the buffer the collective sends
@@ -161,10 +178,50 @@ def measure(args):
     stream = torch.cuda.current_stream().cuda_stream
     frame_bytes = gather.tile[0].numel()
 
+    batches = None
+    if batch:
+        # Frames per batch: as many as keep the batch's intermediates (hit ids, t, linear colour: 20 bytes a pixel, reused by the
+        # next batch) inside the Infinity Cache -- a batch traces all its frames, then shades them.  The batches of a step go
+        # to --batch-groups streams in turn (own handles and buffers per stream), so one batch's shading overlaps the next's tracing.
+        G = max(1, min(args.batch_groups, S, B))
+        nb = args.batch_frames if args.batch_frames > 0 else max(1, min(B, (256 << 20) // max(1, rows * Wl * 23)))
+        nb = min(nb, NB // G)
+        starts = list(range(0, B, nb))
+        def make(slot, i, a0):
+            a1, h0 = min(B, a0 + nb), (i % G) * nb
+            n = a1 - a0
+            return lib.FrameBatch(scenes_[h0:h0 + n], [p] * n, [hit[h0 + j].data_ptr() for j in range(n)], [tbuf[h0 + j].data_ptr() for j in range(n)],
+                                  [lin[h0 + j].data_ptr() for j in range(n)], [gather.tiles[slot].data_ptr() + f * frame_bytes for f in range(a0, a1)])
+        batches = [[make(slot, i, a0) for i, a0 in enumerate(starts)] for slot in range(SLOTS)]
+
+    def render_batches(slot):
+        cur = torch.cuda.current_stream()
+        bs = batches[slot]
+        if G == 1:
+            for b_ in bs:
+                b_.render(cur.cuda_stream)
+            return
+        for k in range(min(G, len(bs))):
+            side[k].wait_stream(cur)
+        for i, b_ in enumerate(bs):
+            b_.render(side[i % G].cuda_stream)
+        for k in range(min(G, len(bs))):
+            cur.wait_stream(side[k])
+
+    if batch:
+        for slot in range(SLOTS):                             # every slot twice: a handle's counter sets alternate per call, and the
+            render_batches(slot); render_batches(slot)        # argument tables of either parity must exist before a capture
+        torch.cuda.synchronize()
+        if not scene.pipeline.endswith("(batched)"):          # the scene prefers another pipeline (a soup): frame by frame then
+            batches, batch = None, False
+
     def render_frames(pp, slot=0, streams=True):
         """The B frames of a step.  With S > 1 frame f goes to stream f % S (fork from / join into the current stream,
         which is what a capturing graph records as parallel branches)."""
         cur = torch.cuda.current_stream()
+        if batches is not None and streams:
+            render_batches(slot)
+            return
         use = side if (streams and S > 1) else []
         for st in use:
             st.wait_stream(cur)
@@ -319,7 +376,7 @@ def measure(args):
                                        ((f"tiles of {BLOCK_ROWS} x {BC} pixels, tile (bx, by) -> rank (bx + by) mod {per_group}" if BC else
                                          f"scanline blocks of {BLOCK_ROWS} rows, block-cyclic") if per_group > 1 else "whole frames") +
                                        "; one RCCL gather of all tiles per step, overlapped with the next step's rendering"),
-                       "frames_per_step": B_total, "ms_per_frame": round(ms_step / B_total, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + f", {S} stream(s)",
+                       "frames_per_step": B_total, "ms_per_frame": round(ms_step / B_total, 5), "launch": ("hipGraph replay" if graph is not None else "eager") + (f", srt_render_device_batch (frames share launches), {len(batches[0])} batch(es) of {nb} on {G} stream(s)" if batches is not None else f", {S} stream(s)"),
                        "primary_rays_per_frame": prim_total, "shadow_rays_per_frame": shad_total},
             "roofline": roof,
             "kernels": {k: {"ms": round(v["ms"], 5), "algorithmic_bytes": v["bytes"]} for k, v in kern.items()},
@@ -389,12 +446,13 @@ def collect_pmc(argv, kernel):
     for a in argv:                                  # the child renders the same workload, briefly
         if skip:
             skip = False; continue
-        if a in ("--steps", "--warmup", "--frames"):
+        if a in ("--steps", "--warmup", "--frames", "--streams"):
             skip = True; continue
-        if a.startswith(("--steps=", "--warmup=", "--frames=")) or a in ("--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"):
+        if a.startswith(("--steps=", "--warmup=", "--frames=", "--streams=")) or a in ("--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"):
             continue
         keep.append(a)
-    child = ["python3", os.path.join(ROOT, "bench.py")] + keep + ["--steps", "2", "--warmup", "1", "--frames", "4", "--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"]
+    child = ["python3", os.path.join(ROOT, "bench.py")] + keep + ["--steps", "2", "--warmup", "1", "--frames", "4", "--streams", "1",       # one stream: the counters of a kernel that runs alone
+                                                              "--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"]
     vals, durs = {}, []
     tmp = tempfile.mkdtemp(prefix="srt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")

@@ -168,6 +168,12 @@ uint32_t srt_cols_owned(const srt_params* p);
 int srt_scene_create(int device, const srt_scene_desc* desc, srt_scene** out);
 int srt_scene_destroy(srt_scene* s);
 
+/* Another handle on the SAME device records (no copy of the geometry; they are freed with the last handle): its own workspace,
+ * counters, statistics and stream, so that several frames of one static scene -- other lights, another camera (ray_matrix),
+ * another share of the frame -- can be in flight at once (streams, srt_render_device_batch) while the records stay hot in L2 /
+ * Infinity Cache once.  srt_scene_update through any of the handles rewrites the records all of them read. */
+int srt_scene_share(srt_scene* src, srt_scene** out);
+
 /* The next frame's geometry into the SAME device allocations (the reference re-transforms and rebuilds everything per frame,
  * simple_raytracer.cpp:534-618): `desc` must have the counts of the scene's current contents (n_objects, n_nodes, n_tris,
  * n_textures, the same triangles textured / with normals), else SRT_ERR_LAYOUT -- create a new scene then.  Texture images are
@@ -186,6 +192,19 @@ int srt_scene_update(srt_scene* s, const srt_scene_desc* desc, void* stream);
  * srt_sync().  */
 int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
                       int32_t* d_hit_id, float* d_t, float* d_rgb_linear, uint8_t* d_rgb8);
+
+/* The frames of a step (the reference's main() renders a 36-frame orbit, simple_raytracer.cpp:534) in ONE pair of launches:
+ * frame i = srt_render_device(scenes[i], &params[i], stream, d_hit_id[i], ...), with bitwise the same outputs.  The handles must
+ * be n DISTINCT scenes on one device (a handle's workspace serves one frame at a time; the same geometry may be created n
+ * times); each output table may be NULL, and so may its entries.  Frames that take the default pipeline for 1..7 light samples
+ * at one common size share the launches, which fills the chip where one frame -- or the eighth of it one of eight GPUs owns --
+ * does not (a silhouette tile occupies its workgroup for the better part of such a launch); any other frame is launched on its
+ * own as srt_render_device would.  The frames' arguments go to device memory once per distinct batch (kept on scenes[0], 128
+ * batches remembered; a handle's counter sets alternate, so a repeated call has two).  That takes blocking calls: a batch first
+ * seen while `stream` is capturing is launched frame by frame -- issue it twice before the capture.  No per-frame times: srt_sync()'s ms_* keep
+ * the values of the last timed render of each handle. */
+int srt_render_device_batch(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream,
+                            int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8);
 
 /* Same, into HOST buffers: allocates nothing per call beyond the scene's workspace, copies back,
  * synchronises.  stats may be NULL. */

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -52,10 +53,19 @@ static inline void alloc_gate() {
 constexpr double PACKET_OVERLAP_THRESHOLD = 150.;     // expected slab tests per ray from which primary rays use the packet walk (measured: DESIGN.md s5)
 constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing between two srt_sync calls
 
+// The device records of a scene: owned by the handle that uploaded them and by every handle made from it with srt_scene_share.
+struct SceneRecords {
+    int device = 0;
+    std::vector<void*> allocs;
+    double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
+    bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
+    ~SceneRecords() { (void)hipSetDevice(device); for (void* d : allocs) (void)hipFree(d); }
+};
+
 struct srt_scene {
     int device = 0;
     DevScene dev{};
-    std::vector<void*> allocs;
+    std::shared_ptr<SceneRecords> rec;
     uint64_t bytes = 0;
     // workspace
     int32_t* ws_hit = nullptr; float* ws_t = nullptr; size_t ws_pixels = 0;
@@ -65,14 +75,15 @@ struct srt_scene {
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
+    struct FrameTable { std::vector<FrameItem> host; FrameItem* dev = nullptr; size_t n = 0; uint64_t stamp = 0; };
+    std::vector<FrameTable> tables;               // argument tables of the batches this handle led (srt_render_device_batch)
+    uint64_t table_clock = 0;
     char pipeline[96] = "";                       // kernels of the last render, in launch order
     uint32_t n_textures = 0; bool has_tex = false;
     void* stage = nullptr; size_t stage_bytes = 0; hipEvent_t staged = nullptr;      // pinned staging of srt_scene_update
     hipStream_t stream = nullptr;                 // the scene's own stream (srt_render, srt_render_async, srt_scene_update with stream NULL)
     unsigned long long* ws_shadow = nullptr; size_t ws_shadow_words = 0;
     uint32_t* ws_qlist = nullptr; uint32_t* d_qcount = nullptr; uint32_t qcap = 0;      // quadrants with hits: 64 shard lists of qcap entries, their counters
-    double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
-    bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
     float* ws_acc = nullptr; float* ws_sub = nullptr; int32_t* ws_sub_hit = nullptr; float* ws_sub_t = nullptr; size_t ws_acc_pixels = 0;
     int n_cu = 256;
     hipEvent_t ev[RING][4] = {};     // start, closest-hit done, shadow done, shade done
@@ -88,7 +99,7 @@ static int upload(srt_scene* s, const T* host, size_t n, const T** out) {
     void* d = nullptr;
     size_t bytes = sizeof(T) * (n ? n : 1);
     HIP_TRY(hipMalloc(&d, bytes));
-    s->allocs.push_back(d);
+    s->rec->allocs.push_back(d);
     if (n) HIP_TRY(hipMemcpy(d, host, sizeof(T) * n, hipMemcpyHostToDevice));
     s->bytes += bytes;
     *out = (const T*)d;
@@ -212,7 +223,8 @@ int srt_scene_destroy(srt_scene* s) {
     if (!s) return SRT_ERR_ARG;
     (void)hipSetDevice(s->device);
     (void)wait_idle(s);
-    for (void* d : s->allocs) (void)hipFree(d);
+    s->rec.reset();                      // frees the records with their last handle
+    for (auto& e : s->tables) (void)hipFree(e.dev);
     if (s->ws_hit) (void)hipFree(s->ws_hit);
     if (s->ws_t) (void)hipFree(s->ws_t);
     if (s->ws_lin) (void)hipFree(s->ws_lin);
@@ -361,6 +373,19 @@ static int check_desc(const srt_scene_desc* d) {
     return SRT_OK;
 }
 
+// What every handle has of its own besides the records: the two counter sets, the quadrant-list counters, the pinned counter image.
+static hipError_t init_handle_state(srt_scene* s) {
+    hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_qcount, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, s->device);
+    if (e == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+    return e;
+}
+
 static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** out) {
     if (!d || !out) return SRT_ERR_ARG;
     *out = nullptr;
@@ -383,6 +408,7 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     srt_scene* s = new (std::nothrow) srt_scene();
     if (!s) return SRT_ERR_OOM;
     s->device = device;
+    s->rec = std::make_shared<SceneRecords>(); s->rec->device = device;
     #define UP(expr) do { rc = (expr); if (rc != SRT_OK) { srt_scene_destroy(s); return rc; } } while (0)
     UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
     UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
@@ -418,19 +444,31 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
     s->n_textures = d->n_textures; s->has_tex = any_tex;
-    s->overlap = overlap;
-    s->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
-    hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_qcount, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
-    hipDeviceProp_t prop;
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
-    if (e == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+    s->rec->overlap = overlap;
+    s->rec->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
+    const hipError_t e = init_handle_state(s);
     if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
     *out = s;
     return SRT_OK;
+}
+
+// A second handle on the SAME device records: its own workspace, counters, stream and statistics, no copy of the geometry.
+static int scene_share_impl(srt_scene* src, srt_scene** out) {
+    if (!src || !out) return SRT_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(src->device));
+    alloc_gate();
+    srt_scene* s = new srt_scene();
+    s->device = src->device; s->dev = src->dev; s->rec = src->rec; s->bytes = src->bytes;
+    s->n_textures = src->n_textures; s->has_tex = src->has_tex;
+    const hipError_t e = init_handle_state(s);
+    if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
+    *out = s;
+    return SRT_OK;
+}
+
+int srt_scene_share(srt_scene* src, srt_scene** out) {
+    return guarded([&] { return scene_share_impl(src, out); });
 }
 
 int srt_scene_create(int device, const srt_scene_desc* d, srt_scene** out) {
@@ -491,8 +529,8 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     if (any_tex) { CP(s->dev.tri_tex, o_tex, nT * 4); CP(s->dev.tri_tc, o_tc, nT * 24); }
     #undef CP
     HIP_TRY(hipEventRecord(s->staged, stream));
-    s->overlap = overlap_estimate(nodes, d->n_nodes, ranges, d->n_objects);
-    s->prefer_packet = s->overlap > PACKET_OVERLAP_THRESHOLD;
+    s->rec->overlap = overlap_estimate(nodes, d->n_nodes, ranges, d->n_objects);
+    s->rec->prefer_packet = s->rec->overlap > PACKET_OVERLAP_THRESHOLD;
     return SRT_OK;
 }
 
@@ -504,7 +542,7 @@ void srt_debug_fail_host_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
 const char* srt_scene_pipeline(const srt_scene* s) { return s ? s->pipeline : ""; }
-double srt_scene_overlap_estimate(const srt_scene* s) { return s ? s->overlap : 0.; }
+double srt_scene_overlap_estimate(const srt_scene* s) { return s ? s->rec->overlap : 0.; }
 
 static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) & 0xffu; }
 
@@ -520,8 +558,15 @@ static int check_params(const srt_params* p) {
     return SRT_OK;
 }
 
+// Frames whose launches srt_render_device_batch holds back to issue them as one grid (k_trace_nq_batch + k_shade_tile_batch).
+struct BatchCollector {
+    std::vector<FrameItem> items;
+    uint32_t wl = 0, rows = 0;           // every held frame writes the same local width and row count: one grid fits all
+    bool accepts(uint32_t w, uint32_t r) { if (items.empty()) { wl = w; rows = r; } return w == wl && r == rows; }
+};
+
 static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, int32_t* d_hit_id, float* d_t,
-                              float* d_rgb_linear, uint8_t* d_rgb8) {
+                              float* d_rgb_linear, uint8_t* d_rgb8, BatchCollector* bc = nullptr) {
     if (!s) return SRT_ERR_ARG;
     int rc = check_params(p);
     if (rc != SRT_OK) return rc;
@@ -667,7 +712,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         //   nq chunked   the round-1 form for 8+ samples (k_shadow_nq, 64 rays in flight, samples cut over blockIdx.z): variant 20
         // camera mode (rays that do not start at the origin): closest hit on the packet kernel, which takes a general ray; the shadow
         // kernels start from the hit point either way
-        const bool pk_closest = fp.cam || variant == 22 || variant == 23 || (variant == 0 && s->prefer_packet && !force_nq);
+        const bool pk_closest = fp.cam || variant == 22 || variant == 23 || (variant == 0 && s->rec->prefer_packet && !force_nq);
         const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
@@ -675,6 +720,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         const bool chunked = p->n_lights >= 8 && !count && variant == 20;
         const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked && !pk_shadow && !pk_closest && variant != 20;     // (variants 11, 17, 18 are configurations of the fused kernel)
         const dim3 grid8x(grid8.x, fp.xcd_rows ? (grid8.y + 7) / 8 * 8 : grid8.y);      // whole tile rows per XCD: y padded to 8 rows
+        bool shaded = false;               // the trace launch shaded its tiles itself
         switch (variant) {
         case 2:                        // one ray per lane + triangle queue
             if (count) hipLaunchKernelGGL((k_closest_hit_q<true>), grid, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr);
@@ -693,6 +739,14 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (count)       hipLaunchKernelGGL((k_closest_hit_pk<true, true, false>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else if (fp.xcd_rows) hipLaunchKernelGGL((k_closest_hit_pk<false, true, true>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else                  hipLaunchKernelGGL((k_closest_hit_pk<false, true, false>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
+            } else if (fused && bc && !count && (p->flags >> 8 & 0xffu) == 0 && !fp.xcd_rows && spp == 1 && bc->accepts(wl, rows)) {
+                // held back: the batch call launches this frame together with the others (same kernels, same arguments)
+                bc->items.push_back(FrameItem{s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr, zero_next, s->d_qcount});
+                std::snprintf(s->pipeline, sizeof(s->pipeline), "k_trace_nq+k_shade_tile (batched)");
+                return SRT_OK;
+            } else if (fused && variant == 28 && !count && !fp.xcd_rows && p->n_lights < 64) {      // 28 (A/B): the whole frame in one launch
+                hipLaunchKernelGGL((k_trace_shade_nq<512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next, s->d_qcount);
+                shaded = true;
             } else if (fused) {        // closest hit + shadow rays in one launch
                 if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
@@ -735,6 +789,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
         std::snprintf(s->pipeline, sizeof(s->pipeline), "%s%s+k_shade_tile", fused ? "k_trace_nq" : (pk_closest ? "k_closest_hit_pk" : "k_closest_hit_nq"),
                       fused || !p->n_lights ? "" : (pk_shadow ? "+k_shadow_pk" : "+k_shadow_nq"));
+        if (shaded) { std::snprintf(s->pipeline, sizeof(s->pipeline), "k_trace_shade_nq"); return SRT_OK; }
         DevParams sp = fp;
         sp.shadow_px_major = pk_shadow ? 1u : 0u;
         hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
@@ -743,7 +798,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     };
 
     // SRT_FLAG_NO_TIMING: no event records (a caller capturing the launches into a hipGraph)
-    hipEvent_t* ev = (p->flags & SRT_FLAG_NO_TIMING) ? nullptr : s->ev[s->ring_count % RING];
+    hipEvent_t* ev = ((p->flags & SRT_FLAG_NO_TIMING) || bc) ? nullptr : s->ev[s->ring_count % RING];      // (a batch has no per-frame times)
     if (ev && !ev[0]) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&ev[i]));      // a ring slot's events are made on first use
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (spp == 1) {
@@ -788,6 +843,89 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
 
 int srt_render_device(srt_scene* s, const srt_params* p, void* stream, int32_t* d_hit_id, float* d_t, float* d_rgb_linear, uint8_t* d_rgb8) {
     return guarded([&] { return render_device_impl(s, p, stream, d_hit_id, d_t, d_rgb_linear, d_rgb8); });
+}
+
+// The argument table of a batch in device memory.  A step re-issues the same batch (same handles, parameters and outputs; the two
+// counter sets of a handle alternate, so two tables), and a captured hipGraph replays it: tables are immutable once made and kept on
+// the first handle of the batch, found again by content.  A new table is allocated and copied with blocking calls, which a capturing
+// stream does not allow: *out stays null then and the caller launches the frames one by one (issue the batch once before capturing).
+constexpr size_t FRAME_TABLES_KEPT = 128;      // (a table is 352 bytes a frame)
+static int frame_table(srt_scene* owner, const std::vector<FrameItem>& items, hipStream_t stream, const FrameItem** out) {
+    const size_t bytes = items.size() * sizeof(FrameItem);
+    *out = nullptr;
+    for (auto& e : owner->tables) {
+        if (e.n != items.size() || std::memcmp(e.host.data(), items.data(), bytes) != 0) continue;
+        e.stamp = ++owner->table_clock;
+        *out = e.dev;
+        return SRT_OK;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(stream, &cap));
+    if (cap != hipStreamCaptureStatusNone) return SRT_OK;
+    if (owner->tables.size() >= FRAME_TABLES_KEPT) {            // forget the table used longest ago (hipFree waits for the device)
+        size_t old = 0;
+        for (size_t k = 1; k < owner->tables.size(); k++) if (owner->tables[k].stamp < owner->tables[old].stamp) old = k;
+        (void)hipFree(owner->tables[old].dev);
+        owner->tables.erase(owner->tables.begin() + old);
+    }
+    alloc_gate();
+    srt_scene::FrameTable e;
+    e.host = items;
+    e.n = items.size(); e.stamp = ++owner->table_clock;
+    if (hipMalloc((void**)&e.dev, bytes) != hipSuccess) { (void)hipGetLastError(); return SRT_ERR_OOM; }
+    const hipError_t err = hipMemcpy(e.dev, e.host.data(), bytes, hipMemcpyHostToDevice);
+    if (err != hipSuccess) { (void)hipFree(e.dev); g_last_hip = (int)err; return SRT_ERR_DEVICE; }
+    owner->tables.push_back(std::move(e));
+    *out = owner->tables.back().dev;
+    return SRT_OK;
+}
+
+// The frames of a step in as few launches as their arguments fit (srt.h).  Every frame goes through render_device_impl -- the same
+// checks, workspaces, light upload and counter sets as a single render; frames that take the fused pipeline at one size are held back
+// and launched together, the others (another pipeline, counting build, supersampling, a different size) are launched as they come.
+static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream_,
+                                    int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8) {
+    if (!n) return SRT_OK;
+    if (!scenes || !params) return SRT_ERR_ARG;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!scenes[i] || scenes[i]->device != scenes[0]->device) return SRT_ERR_ARG;
+        for (uint32_t k = 0; k < i; k++) if (scenes[k] == scenes[i]) return SRT_ERR_ARG;      // a handle's workspace serves one frame at a time
+        const int rc = check_params(&params[i]);                                               // nothing is enqueued if any frame is malformed
+        if (rc != SRT_OK) return rc;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    BatchCollector bc;
+    for (uint32_t i = 0; i < n; i++) {
+        const int rc = render_device_impl(scenes[i], &params[i], stream_, d_hit_id ? d_hit_id[i] : nullptr, d_t ? d_t[i] : nullptr,
+                                          d_rgb_linear ? d_rgb_linear[i] : nullptr, d_rgb8 ? d_rgb8[i] : nullptr, &bc);
+        if (rc != SRT_OK) { bc.items.clear(); for (uint32_t k = 0; k <= i; k++) scenes[k]->ctr_dirty = true; return rc; }   // held frames are dropped: their counter sets may be half-used
+    }
+    const size_t held = bc.items.size();
+    if (!held) return SRT_OK;
+    const FrameItem* table = nullptr;
+    int rc = frame_table(scenes[0], bc.items, stream, &table);
+    const dim3 block(256), g_trace((bc.wl + 7) / 8, (bc.rows + 7) / 8, (uint32_t)held), g_shade((bc.wl + 15) / 16, (bc.rows + 15) / 16, (uint32_t)held);
+    if (rc == SRT_OK && table) {
+        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 6, 16>), g_trace, block, 0, stream, table);
+        if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
+        if (rc == SRT_OK) {
+            hipLaunchKernelGGL(k_shade_tile_batch, g_shade, block, 0, stream, table);
+            if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
+        }
+    } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
+        for (const FrameItem& it : bc.items) {
+            hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), dim3(g_trace.x, g_trace.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
+            hipLaunchKernelGGL(k_shade_tile, dim3(g_shade.x, g_shade.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+            if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
+        }
+    }
+    if (rc != SRT_OK) for (uint32_t k = 0; k < n; k++) scenes[k]->ctr_dirty = true;       // the set the shading would have zeroed
+    return rc;
+}
+
+int srt_render_device_batch(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream,
+                            int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8) {
+    return guarded([&] { return render_device_batch_impl(n, scenes, params, stream, d_hit_id, d_t, d_rgb_linear, d_rgb8); });
 }
 
 int srt_sync(srt_scene* s, srt_stats* stats) {

@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
             if (shadowed && valid) atomicOr(&L.mask[lg], 1u << pl);
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < Lg) reinterpret_cast<uint16_t*>(shadow_bits)[(tile_index * p.n_lights + l0 + lane) * 4 + wave] = (uint16_t)L.mask[lane];
+        if (shadow_bits && lane < Lg) reinterpret_cast<uint16_t*>(shadow_bits)[(tile_index * p.n_lights + l0 + lane) * 4 + wave] = (uint16_t)L.mask[lane];
         __builtin_amdgcn_wave_barrier();
     }
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
@@ -1065,75 +1065,11 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
                                          l_begin, l_chunk == 0xffffffffu ? 0xffffffffu : l_begin + l_chunk);
 }
 
-// =================================================================================================
-// Kernel 1+2a fused (shipped): the wavefront that found its 4x4 tile's closest hits goes straight on to the
-// tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
-// a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
-// =================================================================================================
-// ROOTS_AGAIN: the round-1 form (every wave re-tests the roots), for A/B
-template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false>
-__global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
-                                                  float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                  unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t nq_all[4][NQCAP];
-    __shared__ uint32_t tq_all[4][LQ_WORDS];
-    __shared__ unsigned long long best_all[4][NQ_P];
-    __shared__ float4 dir_all[4][NQ_P];
-    __shared__ ShadowLds<RS> lds_all[4];
-    const uint32_t wave = threadIdx.x >> 6;
-    int32_t id; float t; V3 d;
-    unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
-    SRT_STAMP(k0);
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own 4 MiB L2).  When the
-    // scene's records are far bigger than an L2 (XCD_ROWS; the host pads the grid's y extent to a multiple of 8 rows), every
-    // XCD gets whole rows of tiles -- XCD j walks tile rows j, j + 8, ... left to right -- so that neighbouring tiles, which
-    // read the same nodes and triangles, hit in the same L2: 1 M-triangle soup -15 %.  For a scene of a few MB the plain
-    // order is as good or slightly better (K3: +1 % with the row deal, +2 % with a run-time switch), so it has its own build.
-    const uint32_t gx = gridDim.x;
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (XCD_ROWS) {
-        const uint32_t w = blockIdx.y * gx + blockIdx.x, idx = w >> 3;
-        by = (idx / gx) * 8u + (w & 7u); bx = idx % gx;
-        if (by >= (p.rows + 7u) / 8u) return;
-    }
-    __shared__ uint32_t root_pass[64];
-    const bool roots_done = !COUNT && !ROOTS_AGAIN && s.n_objects <= 32u;              // wave 0 tests every root for the tile's 64 rays first
-    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
-    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
-                                                  roots_done ? root_pass + wave * 16 : nullptr);
-    __builtin_amdgcn_wave_barrier();
-    shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
-#ifdef SRT_DIAG
-    SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
-#endif
-}
-
-// =================================================================================================
-// Kernel 2b: shading, one thread per hit pixel (same tiles).  softShadow:348-401 (texture fetch,
-// light-sample loop with in-order f32 sum, /5 for shadowed samples, Reinhard + gamma),
-// phongIllumination:144-200, quantiser :447-449, black -> background (:518, drawImage:476-487).
-// Pure ALU, no traversal; misses were finished by the closest-hit kernel.
-// =================================================================================================
-__global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
-                                                    const float* __restrict__ t_in,
-                                                    const unsigned long long* __restrict__ shadow_bits,
-                                                    float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                    unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
-    if (counters_next) zero_next_counters(counters_next);
-    // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
-    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
-#ifdef SRT_DIAG
-    rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
-#endif
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t px, r;
-    if (!tile_pixel(p, px, r)) return;
+// One hit pixel: `shadowed(l)` says whether light sample l's shadow ray was blocked.
+template <typename SH>
+__device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevParams& p, const int32_t id, const float t, const uint32_t px, const uint32_t r,
+                                                SH shadowed, float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8) {
     const size_t pix = (size_t)r * p.W + px;
-    const int32_t id = hit_id[pix];
-    if (id < 0) return;
-    const size_t tile_index = (size_t)(blockIdx.y * 2 + (wave >> 1)) * ((p.W + 7) / 8) + blockIdx.x * 2 + (wave & 1);   // 8x8 tile
-    const float t = t_in[pix];
     const V3 o = ray_origin(p);
     const V3 d = primary_dir(p, px, image_row(p, r));
     const int32_t obj = s.tri_obj[id];
@@ -1166,21 +1102,11 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
                                 (bc.x * n9[2] + bc.y * n9[5]) + bc.z * n9[8]));
     }
     V3 sum = mk(0.0f, 0.0f, 0.0f);
-    // shadow bits, tile-major (node-queue kernels): per tile and light sample one word, one 16-bit field per 4x4 quadrant (the wave
-    // that traced it), bit = y * 4 + x inside the quadrant; pixel-major (packet shadow kernel): per pixel one word per 64 samples
-    const uint32_t n_lch = (p.n_lights + 63u) >> 6;
-    const unsigned long long* sb = p.shadow_px_major ? shadow_bits + pix * n_lch : shadow_bits + tile_index * p.n_lights;
-    const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
-    unsigned long long word = 0ull;                        // pixel-major: the pixel's shadow bits of the current 64 samples, loaded once per 64
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
-        bool shadowed;
-        if (p.shadow_px_major) {
-            if ((l & 63u) == 0u) word = sb[l >> 6];
-            shadowed = (word >> (l & 63u)) & 1ull;
-        } else shadowed = (sb[l] >> sbit) & 1ull;
+        const bool sd = shadowed(l);
         V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
-        if (shadowed) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);       // :369
+        if (sd) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);             // :369
         sum = sum + c;                                                                          // :370
     }
     int q0 = quant1(tone1(sum.x, p.reinhard, p.gamma));                                         // :391-398,447-449
@@ -1191,6 +1117,167 @@ __global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, con
         if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }   // :518, :476-487
         rgb8[pix * 3] = (uint8_t)q0; rgb8[pix * 3 + 1] = (uint8_t)q1; rgb8[pix * 3 + 2] = (uint8_t)q2;
     }
+}
+
+// =================================================================================================
+// Kernel 1+2a fused (shipped): the wavefront that found its 4x4 tile's closest hits goes straight on to the
+// tile's shadow rays -- hit ids, t and the hit object are still in registers, the queues are reused, and
+// a frame is two launches (this + shading).  Workgroup = 8x8 pixel tile, 4 waves.
+// =================================================================================================
+// ROOTS_AGAIN: the round-1 form (every wave re-tests the roots), for A/B
+// SHADE: the frame in ONE launch.  The tile's four waves finish at different times and none waits: each leaves its 16 hit ids / t
+// in LDS (its shadow masks are there already) and bumps an LDS counter, and the wave that finds the other three done shades the
+// tile's 64 pixels, one per lane -- what k_shade_tile does in a second launch from hit ids, t and shadow words re-read from
+// memory.  Up to 63 light samples (one group of masks); `shadow_bits` may be null then (nobody reads the words).
+template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false>
+__device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                              float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
+                                              unsigned long long* __restrict__ counters_next = nullptr, uint32_t* __restrict__ qcount = nullptr) {
+    __shared__ uint32_t fin_count;
+    __shared__ int32_t fin_id[64];
+    __shared__ float fin_t[64];
+    if (SHADE) {
+        if (threadIdx.x == 0) fin_count = 0u;              // (the barrier in finish_background_tile orders this before the first bump)
+        if (counters_next) zero_next_counters(counters_next);
+        if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;
+    }
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][LQ_WORDS];
+    __shared__ unsigned long long best_all[4][NQ_P];
+    __shared__ float4 dir_all[4][NQ_P];
+    __shared__ ShadowLds<RS> lds_all[4];
+    const uint32_t wave = threadIdx.x >> 6;
+    int32_t id; float t; V3 d;
+    unsigned long long k0 = 0, k1 = 0; (void)k0; (void)k1;
+    SRT_STAMP(k0);
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own 4 MiB L2).  When the
+    // scene's records are far bigger than an L2 (XCD_ROWS; the host pads the grid's y extent to a multiple of 8 rows), every
+    // XCD gets whole rows of tiles -- XCD j walks tile rows j, j + 8, ... left to right -- so that neighbouring tiles, which
+    // read the same nodes and triangles, hit in the same L2: 1 M-triangle soup -15 %.  For a scene of a few MB the plain
+    // order is as good or slightly better (K3: +1 % with the row deal, +2 % with a run-time switch), so it has its own build.
+    const uint32_t gx = gridDim.x;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (XCD_ROWS) {
+        const uint32_t w = blockIdx.y * gx + blockIdx.x, idx = w >> 3;
+        by = (idx / gx) * 8u + (w & 7u); bx = idx % gx;
+        if (by >= (p.rows + 7u) / 8u) return;
+    }
+    __shared__ uint32_t root_pass[64];
+    const bool roots_done = !COUNT && !ROOTS_AGAIN && s.n_objects <= 32u;              // wave 0 tests every root for the tile's 64 rays first
+    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
+    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
+                                                  roots_done ? root_pass + wave * 16 : nullptr);
+    __builtin_amdgcn_wave_barrier();
+    shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
+#ifdef SRT_DIAG
+    SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1);
+#endif
+    if (SHADE) {
+        const uint32_t lane = threadIdx.x & 63;
+        if (lane < NQ_P) { fin_id[wave * NQ_P + lane] = id; fin_t[wave * NQ_P + lane] = t; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t before = 0;
+        if (lane == 0) before = atomicAdd(&fin_count, 1u);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before != 3u) return;                          // a neighbour is still walking: it will shade the tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t q = lane >> 4, pl = lane & 15u;       // lane -> (quadrant = the wave that traced it, pixel of the quadrant)
+        const uint32_t px = bx * 8 + (q & 1u) * 4 + (pl & 3u), r = by * 8 + (q >> 1) * 4 + (pl >> 2);
+        const int32_t hid = fin_id[lane];
+        if (hid >= 0 && pixel_live(p, px, r)) {
+            const uint32_t* mask = lds_all[q].mask;
+            shade_hit_pixel(s, p, hid, fin_t[lane], px, r, [&](uint32_t l) -> bool { return (mask[l] >> pl) & 1u; }, rgb_linear, rgb8);
+        }
+    }
+}
+
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false>
+__global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                  float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                  unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
+    trace_nq_body<COUNT, NQCAP, FILTER, RS, XCD_ROWS, ROOTS_AGAIN>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, counters);
+}
+// closest hit, shadow rays and shading of a frame in one launch (SHADE)
+template <int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false>
+__global__ __launch_bounds__(256, MINW) void k_trace_shade_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
+                                                        float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                        unsigned long long* __restrict__ counters, unsigned long long* __restrict__ counters_next,
+                                                        uint32_t* __restrict__ qcount) {
+    trace_nq_body<false, NQCAP, FILTER, RS, XCD_ROWS, false, true>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, counters, counters_next, qcount);
+}
+
+// ---- several frames in ONE launch (srt_render_device_batch): blockIdx.z selects the frame ------------------------------------
+// The frames of an orbit are independent renders (own scene, own parameters, own outputs).  A tile on the bunny's silhouette keeps
+// its workgroup busy for ~60 us (~80 with the CU fully occupied), and the chip holds 1,536 workgroups of this kernel at a time: a
+// launch lasts a whole number of such rounds.  The 1080p frame has ~2,500 heavy tiles (1.6 rounds in 0.125 ms); the eighth of it
+// that one of eight GPUs owns has ~310 and still takes 0.072 ms as its own launch, nine eighths launched together take 0.199 ms
+// (two rounds) where 0.142 would be their share -- measured with tools/strip_probe.py, whatever the height of the scanline blocks.
+// With ALL frames of a step in one grid the rounds are filled.  A frame's arguments come from a table in device memory (352 bytes
+// a frame; the kernarg segment's 4 KiB would hold ten), read with scalar loads: the index is blockIdx.z, the table is read-only.
+struct FrameItem {
+    DevScene s; DevParams p;
+    int32_t* hit_id; float* t_out; float* rgb_linear; uint8_t* rgb8;
+    unsigned long long* shadow_bits; unsigned long long* counters; unsigned long long* counters_next; uint32_t* qcount;
+};
+template <int NQCAP, bool FILTER, int MINW, int RS>
+__global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameItem* __restrict__ items) {
+    const FrameItem it = items[blockIdx.z];
+    trace_nq_body<false, NQCAP, FILTER, RS, false, false>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
+}
+
+// =================================================================================================
+// Kernel 2b: shading, one thread per hit pixel (same tiles).  softShadow:348-401 (texture fetch,
+// light-sample loop with in-order f32 sum, /5 for shadowed samples, Reinhard + gamma),
+// phongIllumination:144-200, quantiser :447-449, black -> background (:518, drawImage:476-487).
+// Pure ALU, no traversal; misses were finished by the closest-hit kernel.
+// =================================================================================================
+__device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevParams& p, const int32_t* __restrict__ hit_id,
+                                                const float* __restrict__ t_in,
+                                                const unsigned long long* __restrict__ shadow_bits,
+                                                float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
+    if (counters_next) zero_next_counters(counters_next);
+    // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
+    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
+#ifdef SRT_DIAG
+    rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
+#endif
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t px, r;
+    if (!tile_pixel(p, px, r)) return;
+    const size_t pix = (size_t)r * p.W + px;
+    const int32_t id = hit_id[pix];
+    if (id < 0) return;
+    const size_t tile_index = (size_t)(blockIdx.y * 2 + (wave >> 1)) * ((p.W + 7) / 8) + blockIdx.x * 2 + (wave & 1);   // 8x8 tile
+    const float t = t_in[pix];
+    // shadow bits, tile-major (node-queue kernels): per tile and light sample one word, one 16-bit field per 4x4 quadrant (the wave
+    // that traced it), bit = y * 4 + x inside the quadrant; pixel-major (packet shadow kernel): per pixel one word per 64 samples
+    const uint32_t n_lch = (p.n_lights + 63u) >> 6;
+    const unsigned long long* sb = p.shadow_px_major ? shadow_bits + pix * n_lch : shadow_bits + tile_index * p.n_lights;
+    const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
+    unsigned long long word = 0ull;                        // pixel-major: the pixel's shadow bits of the current 64 samples, loaded once per 64
+    const bool px_major = p.shadow_px_major != 0u;
+    shade_hit_pixel(s, p, id, t, px, r, [&](uint32_t l) -> bool {
+        if (px_major) {
+            if ((l & 63u) == 0u) word = sb[l >> 6];
+            return (word >> (l & 63u)) & 1ull;
+        }
+        return (sb[l] >> sbit) & 1ull;
+    }, rgb_linear, rgb8);
+}
+
+__global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+                                                    const float* __restrict__ t_in,
+                                                    const unsigned long long* __restrict__ shadow_bits,
+                                                    float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
+                                                    unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
+    shade_tile_body(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount);
+}
+__global__ __launch_bounds__(256) void k_shade_tile_batch(const FrameItem* __restrict__ items) {      // the shading of the frames k_trace_nq_batch traced
+    const FrameItem it = items[blockIdx.z];
+    shade_tile_body(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
 }
 
 // =================================================================================================

@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 
 # every symbol include/srt.h declares
-ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy", "srt_scene_update",
-               "srt_render_device", "srt_render", "srt_render_async", "srt_host_alloc", "srt_host_free", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
+ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy", "srt_scene_update", "srt_scene_share",
+               "srt_render_device", "srt_render_device_batch", "srt_render", "srt_render_async", "srt_host_alloc", "srt_host_free", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
                "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
                "srt_debug_fail_host_allocs", "srt_scene_pipeline", "srt_scene_overlap_estimate")
 
@@ -53,10 +53,14 @@ def load():
         L.srt_scene_create.restype = C.c_int
         L.srt_scene_update.argtypes = [C.c_void_p, C.POINTER(abi.SceneDesc), C.c_void_p]
         L.srt_scene_update.restype = C.c_int
+        L.srt_scene_share.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.srt_scene_share.restype = C.c_int
         L.srt_scene_destroy.argtypes = [C.c_void_p]
         L.srt_scene_destroy.restype = C.c_int
         L.srt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.srt_render_device.restype = C.c_int
+        L.srt_render_device_batch.argtypes = [C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(abi.Params), C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
+        L.srt_render_device_batch.restype = C.c_int
         L.srt_render.argtypes = [C.c_void_p, C.POINTER(abi.Params), _i32p, _f32p, _f32p, _u8p, C.POINTER(abi.Stats)]
         L.srt_render.restype = C.c_int
         L.srt_render_async.argtypes = [C.c_void_p, C.POINTER(abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -105,6 +109,15 @@ class DeviceScene:
         d = flat.desc()
         _check(self.L.srt_scene_create(device, C.byref(d), C.byref(h)), "srt_scene_create")
         self.h = h
+
+    def share(self):
+        """srt_scene_share: another handle (own workspace and counters) on this scene's device records."""
+        o = object.__new__(DeviceScene)
+        o.L, o.flat, o.device = self.L, self.flat, self.device
+        h = C.c_void_p()
+        _check(self.L.srt_scene_share(self.h, C.byref(h)), "srt_scene_share")
+        o.h = h
+        return o
 
     def update(self, flat: abi.FlatScene, stream=0):
         """srt_scene_update: new geometry with the same counts into the existing device allocations (asynchronous on `stream`)."""
@@ -167,6 +180,30 @@ class DeviceScene:
         st = abi.Stats()
         _check(self.L.srt_sync(self.h, C.byref(st)), "srt_sync")
         return st.as_dict()
+
+
+class FrameBatch:
+    """The argument tables of one srt_render_device_batch call, built once (a step of a bench or an orbit re-issues the same call):
+    `scenes` are distinct DeviceScenes, `params` one abi.Params per frame, the outputs lists of raw device pointers (ints) or None."""
+
+    def __init__(self, scenes, params, hit_id=None, t=None, rgb_linear=None, rgb8=None):
+        n = len(scenes)
+        assert len(params) == n
+        self.L, self.n, self.scenes = load(), n, list(scenes)
+        self.h = (C.c_void_p * n)(*[s.h for s in scenes])
+        self.p = (abi.Params * n)()
+        for i, q in enumerate(params):
+            C.memmove(C.byref(self.p[i]), C.byref(q), C.sizeof(abi.Params))
+        self._keep = list(params)             # the light arrays the params point to
+        def table(v):
+            if v is None:
+                return None
+            assert len(v) == n
+            return (C.c_void_p * n)(*[C.c_void_p(int(x) if x else 0) for x in v])
+        self.out = [table(v) for v in (hit_id, t, rgb_linear, rgb8)]
+
+    def render(self, stream=0):
+        _check(self.L.srt_render_device_batch(self.n, self.h, self.p, C.c_void_p(stream), *self.out), "srt_render_device_batch")
 
 
 def _f(a):

@@ -143,6 +143,88 @@ def test_tiles_dealt_in_two_dimensions_reassemble_bitwise(srt, name, W, H, L):
         assert np.array_equal(bits(lin.reshape(H, W, 3)), bits(whole["rgb_linear"])) and np.array_equal(bits(t.reshape(H, W)), bits(whole["t"]))
 
 
+def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
+    """srt_render_device_batch: 14 frames (two scenes, different lights, a scanline-block share, and three frames that cannot share
+    a launch: 9 light samples, another size, the counting build) come out bit for bit as 14 srt_render calls do, and every
+    handle's statistics are its own frame's.  (Output buffers: pinned host memory from srt_host_alloc, which the device addresses
+    directly -- no second HIP user in the test process.)"""
+    import ctypes as C
+    L_ = srt.load()
+    pinned = []
+    def buf(shape, dtype, fill):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = L_.srt_host_alloc(n); assert ptr
+        pinned.append(ptr)
+        a = np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=dtype).reshape(shape)
+        a[...] = fill
+        return a
+    ga, gb = gu.GoldenScene("ground_bunny"), gu.GoldenScene("cubes4_a0")
+    W, H = 192, 108
+    frames = []
+    for k in range(11):                                       # 11 frames of one size: they share the launches
+        g = ga if k % 3 else gb
+        light = g.light.copy(); light[0] += 40.0 * k
+        frames.append((g, abi.make_params(W, H, abi.light_staircase(light, 1 + k % 3), block_rows=8, block_first=1, block_stride=3)))
+    frames.append((ga, ga.params(W, H, 9)))                                     # packet shadow pipeline: launched on its own
+    frames.append((gb, gb.params(128, 96, 2)))                                  # fused, but another size: second group
+    frames.append((ga, abi.make_params(W, H, abi.light_staircase(ga.light, 2), block_rows=8, block_first=1, block_stride=3, flags=abi.SRT_FLAG_COUNT_WORK)))
+    # frames of the same scene share ONE copy of its device records (srt_scene_share); the handle that uploaded them goes first
+    first = {id(ga): srt.DeviceScene(ga.flat), id(gb): srt.DeviceScene(gb.flat)}
+    handles = [first[id(g)].share() for g, _ in frames]
+    for h in first.values():
+        h.close()                                             # the records live on with the handles that share them
+    bufs = []
+    for (g, p), h in zip(frames, handles):
+        r, w = h.rows(p), h.cols(p)
+        bufs.append((buf((r, w), np.int32, -7), buf((r, w), np.float32, 0), buf((r, w, 3), np.float32, 0), buf((r, w, 3), np.uint8, 0)))
+    fb = srt.FrameBatch(handles, [p for _, p in frames], *[[b[k].ctypes.data for b in bufs] for k in range(4)])
+    for rep in range(2):                                      # twice: both counter sets of every handle
+        for b in bufs:
+            b[0][...] = -7
+        fb.render()
+        for k, ((g, p), h, b) in enumerate(zip(frames, handles, bufs)):
+            st = h.sync()
+            one = srt.DeviceScene(g.flat)
+            o = one.render(p)
+            assert np.array_equal(b[0], o["hit_id"]), k
+            assert np.array_equal(bits(b[1]), bits(o["t"])), k
+            assert np.array_equal(bits(b[2]), bits(o["rgb_linear"])), k
+            assert np.array_equal(b[3], o["rgb8"]), k
+            for key in ("hit_rays", "shadow_rays", "primary_rays", "rows", "node_tests", "tri_tests"):
+                assert st[key] == o["stats"][key], (k, key)
+            one.close()
+    assert handles[0].pipeline == "k_trace_nq+k_shade_tile (batched)" and "k_shadow_pk" in handles[11].pipeline
+    # a handle twice in one call: refused before anything is enqueued
+    with pytest.raises(srt.SrtError) as e:
+        srt.FrameBatch([handles[0], handles[0]], [frames[0][1]] * 2).render()
+    assert e.value.code == abi.SRT_ERR_ARG
+    bad = abi.make_params(W, H, abi.light_staircase(ga.light, 1)); bad.spp = 3
+    with pytest.raises(srt.SrtError):
+        srt.FrameBatch(handles[:2], [frames[0][1], bad]).render()
+    # more distinct batches than a handle remembers argument tables for (128): the oldest are dropped, results stay right
+    for k in range(132):
+        light = ga.light.copy(); light[1] -= 2.0 * k
+        pk = abi.make_params(W, H, abi.light_staircase(light, 2))
+        outs = [buf((H, W), np.int32, -7) for _ in range(2)]
+        srt.FrameBatch(handles[:2], [pk, pk], [o.ctypes.data for o in outs]).render()
+        handles[0].sync(); handles[1].sync()
+        assert np.array_equal(outs[0], outs[1]) or frames[0][0] is not frames[1][0]
+        if k in (0, 131):
+            one = srt.DeviceScene(frames[1][0].flat)
+            assert np.array_equal(outs[1], one.render(pk)["hit_id"])
+            one.close()
+    bufs[0][0][...] = -7
+    fb.render()                                                # and the handles still render
+    for h in handles:
+        h.sync()
+    assert np.array_equal(bufs[0][0], srt.DeviceScene(frames[0][0].flat).render(frames[0][1])["hit_id"])
+    for h in handles:
+        h.close()
+    del bufs
+    for ptr in pinned:
+        L_.srt_host_free(ptr)
+
+
 @pytest.mark.parametrize("L", [1, 9])
 def test_camera_mode_matches_oracle(srt, oracle, L):
     """Camera mode (srt_params.ray_matrix; EXTENSION, pinned by the oracle run in the same mode only): the scene of the reference's
@@ -449,6 +531,24 @@ def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
     d = ds.render(g.params(W, H, L))                      # shipped pipeline, non-counting build
     assert np.array_equal(d["hit_id"], o["hit_id"]) and np.array_equal(bits(d["t"]), bits(o["t"]))
     assert np.array_equal(bits(d["rgb_linear"]), bits(o["rgb_linear"])) and np.array_equal(d["rgb8"], o["rgb8"])
+
+
+@pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 190, 107, 1), ("cubes4_a0", 128, 96, 3), ("texquad", 64, 48, 2), ("cubes4_a40", 150, 100, 7),
+                                        ("spheres6", 160, 120, 1)])
+def test_frame_in_one_launch_matches_two_launches(srt, name, W, H, L):
+    """The tile's last wave shades it inside the trace launch (k_trace_shade_nq): bitwise what the trace launch + k_shade_tile
+    give, whole frames and a scanline-block share, sizes that are no multiple of the tile."""
+    g, ds = device_scene(srt, name)
+    for kw in ({}, dict(block_rows=8, block_first=1, block_stride=3)):
+        a = ds.render(g.params(W, H, L, flags=10 << 8, **kw))             # unfused: closest hit, shadow, shade
+        b = ds.render(g.params(W, H, L, flags=28 << 8, **kw))
+        assert ds.pipeline == "k_trace_shade_nq"
+        for k in ("hit_id", "rgb8"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(bits(a["t"]), bits(b["t"])) and np.array_equal(bits(a["rgb_linear"]), bits(b["rgb_linear"]))
+        assert a["stats"]["hit_rays"] == b["stats"]["hit_rays"] == int((b["hit_id"] >= 0).sum())
+        c = ds.render(g.params(W, H, L, **kw))                             # and a render after it finds clean counters
+        assert c["stats"]["hit_rays"] == b["stats"]["hit_rays"] and np.array_equal(c["rgb8"], b["rgb8"])
 
 
 def test_big_leaves_and_signed_zero_t(srt, oracle):
