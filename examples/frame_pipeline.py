@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--builders", type=lambda v: [int(x) for x in v.split(",")], default=[2, 3, 4], help="frames built concurrently in mode 3b, e.g. 2,3,4")
     a = ap.parse_args()
     W, H, N = a.width, a.height, a.frames
     bunny, cube = gu.load_mesh("bunny"), gu.load_mesh("cube")
@@ -128,19 +129,21 @@ def main():
     print(f" 3. pipelined (next frame's hierarchies built during this frame's flatten / upload / render / collect): {wall:.3f} ms per frame, exact "
           f"(drop-in call {np.median(t_render):.3f} ms, then {np.median(t_join):.3f} ms more until the next frame's scene is built)")
 
-    # ---- 3b. two builder threads: the hierarchy build has serial stretches, two frames' builds fill each other's gaps --------------
+    # ---- 3b. several frames being built at any time: the hierarchy build has serial stretches (the top-level sorts), the builds of
+    # different frames fill each other's gaps
     import concurrent.futures as cf
-    with cf.ThreadPoolExecutor(2) as ex:
-        fut = [ex.submit(build_frame, 0, bunny, cube), ex.submit(build_frame, 1, bunny, cube)]
-        t0 = time.perf_counter()
-        for f in range(N):
-            om = fut[f % 2].result()
-            fut[f % 2] = ex.submit(build_frame, f + 2, bunny, cube)
-            n = r.render(om, W, H, LIGHT, image=False)
-        wall2 = (time.perf_counter() - t0) * 1e3 / N
-        for x in fut:
-            x.result()
-    print(f" 3b. pipelined, two frames being built at any time: {wall2:.3f} ms per frame, exact")
+    for nb in a.builders:
+        with cf.ThreadPoolExecutor(nb) as ex:
+            fut = [ex.submit(build_frame, k, bunny, cube) for k in range(nb)]
+            t0 = time.perf_counter()
+            for f in range(N):
+                om = fut[f % nb].result()
+                fut[f % nb] = ex.submit(build_frame, f + nb, bunny, cube)
+                n = r.render(om, W, H, LIGHT, image=False)
+            wall2 = (time.perf_counter() - t0) * 1e3 / N
+            for x in fut:
+                x.result()
+        print(f" 3b. pipelined, {nb} frames being built at any time: {wall2:.3f} ms per frame, exact")
 
     # ---- 4. camera mode: world-space scene, hierarchies built once, one matrix per frame ---------------------------------------
     om = build_frame(0, bunny, cube)

@@ -1022,7 +1022,8 @@ static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t 
         }
     });
     for (uint32_t x = 0; x < W; x++) col[x + 1] += col[x];
-    out.imagePoints.resize(col[W]); out.imageColors.resize(col[W]);
+    // (resize value-initialises: 20 bytes per emitted pixel of serial zero fill -- the two vectors on two threads)
+    parallel_for(2, 1, [&](size_t b, size_t e) { for (size_t k = b; k < e; k++) { if (k == 0) out.imagePoints.resize(col[W]); else out.imageColors.resize(col[W]); } });
     parallel_for(W, 64, [&](size_t x0, size_t x1) {
         for (size_t x = x0; x < x1; x++) {
             size_t k = col[x];

@@ -645,7 +645,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
     const bool coarse_grid = variant == 27;                // 27: variant 0 with 2 x 2 tiles per workgroup in the unfused closest-hit launch (A/B, not shipped)
-    if (force_nq || variant == 25 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -773,6 +773,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             const uint64_t max_units = (uint64_t)n_tiles * 4u * 2u * ((p->n_lights + 7) / 8);
             const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * 8 ? max_units / 4 + 1 : (uint64_t)s->n_cu * 8);
             if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
+            else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
             else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // records through LDS windows (A/B)
             else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());

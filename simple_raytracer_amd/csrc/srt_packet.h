@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
 // =================================================================================================
 // qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) units handed out per fetch shard; counters
 // QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
-template <bool COUNT, bool FILTER, bool WINDOWS>
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false>
 __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                    uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
                                                    unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
@@ -346,8 +346,9 @@ __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, 
         if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);        // the next unit's number: in flight during this walk
         // unit -> (chunk of 8 samples, entry, pixel group): consecutive units are different ENTRIES, so that the waves that
         // start together do not all read the same quadrant
-        const uint32_t lc = u / (2u * n_entries), ue = u - lc * 2u * n_entries;
-        const uint32_t g = ue / n_entries, e = ue - g * n_entries;
+        uint32_t lc, g, e;
+        if (ENTRY_MAJOR) { e = u / upe; const uint32_t w_ = u - e * upe; lc = w_ >> 1; g = w_ & 1u; }
+        else { lc = u / (2u * n_entries); const uint32_t ue = u - lc * 2u * n_entries; g = ue / n_entries; e = ue - g * n_entries; }
         const unsigned long long above = __ballot(incl > e);                 // first shard list whose inclusive prefix exceeds e
         const uint32_t shard = (uint32_t)__builtin_ctzll(above);
         const uint32_t excl = (uint32_t)__shfl((int)(incl - cnt), (int)shard, 64);

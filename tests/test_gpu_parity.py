@@ -851,7 +851,7 @@ def test_many_light_samples_on_deep_trees(srt, oracle, name, W, H, L):
     lights = abi.light_staircase(g.light, L)
     c = oracle.render(g.flat, abi.make_params(W, H, lights, flags=abi.SRT_FLAG_COUNT_WORK))
     assert (c["hit_id"] >= 0).sum() > 1000
-    for flags in (0, 17 << 8, 20 << 8, 21 << 8, 22 << 8, 27 << 8, abi.SRT_FLAG_COUNT_WORK, (22 << 8) | abi.SRT_FLAG_COUNT_WORK):      # 27: 2 x 2 tiles per closest-hit workgroup
+    for flags in (0, 17 << 8, 20 << 8, 21 << 8, 22 << 8, 27 << 8, 29 << 8, abi.SRT_FLAG_COUNT_WORK, (22 << 8) | abi.SRT_FLAG_COUNT_WORK):      # 27: 2 x 2 tiles per closest-hit workgroup, 29: shadow units in entry order
         o = ds.render(abi.make_params(W, H, lights, flags=flags))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), flags
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max())), flags
