@@ -355,6 +355,8 @@ def measure(args):
         if pmc is None and world == 1:
             pmc = committed_pmc(args.workload, dom, W, H, L)
         roof = roofline_block(dom, dom_ms, kern[dom]["bytes"], effective, pmc, g)
+        roof["kernel_ms_note"] = ("HIP events around eager launches on ONE stream (the kernel running alone, as in profiles/*_kernel_stats.csv and the --pmc "
+                                  f"passes); the timed region overlaps the frames of a step on {S} stream(s), where a per-kernel duration is not defined")
         out = {
             "metric": "Mrays/sec (primary+shadow) at 1920x1080; max per-pixel |dRGB| vs CPU ref", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
