@@ -1108,6 +1108,63 @@ ImageData Renderer::renderFromCamera(const vec2& imageSize, const vec4& lightPos
     return collect();
 }
 
+MultiRenderer::MultiRenderer(const std::vector<int>& devices, uint32_t blockRows) : blockRows_(blockRows ? blockRows : 8) {
+    if (devices.empty()) throw std::runtime_error("MultiRenderer: no devices");
+    for (int d : devices) { Part p; p.device = d; parts_.push_back(p); }
+}
+MultiRenderer::~MultiRenderer() {
+    for (Part& p : parts_) { if (p.scene) srt_scene_destroy(p.scene); if (p.rgb8) srt_host_free(p.rgb8); }
+}
+
+ImageData MultiRenderer::render(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount) {
+    const uint32_t W = (uint32_t)imageSize.x, H = (uint32_t)imageSize.y, N = (uint32_t)parts_.size();
+    FlatScene flat = flattenScene(objManager);                          // once; every device gets the same records
+    srt_scene_desc d = flat.desc();
+    std::vector<float> lights((size_t)lightAmount * 3);
+    const float base[3] = { lightPos.x, lightPos.y, lightPos.z };       // vec4 -> const vec3& drops w (:517 -> :405)
+    srt_light_staircase(base, (uint32_t)lightAmount, lights.data());
+    auto params_of = [&](uint32_t k) {
+        srt_params p;
+        srt_params_default(&p, W, H);
+        p.n_lights = (uint32_t)lightAmount; p.light_pos = lights.data();
+        p.background[0] = p.background[1] = p.background[2] = 0;         // black = not emitted (:518)
+        p.block_rows = blockRows_; p.block_first = k; p.block_stride = N;
+        return p;
+    };
+    // enqueue everywhere first (upload + render + read-back on each scene's own stream), then wait
+    for (uint32_t k = 0; k < N; k++) {
+        Part& pt = parts_[k];
+        int rc = pt.scene ? srt_scene_update(pt.scene, &d, nullptr) : SRT_ERR_LAYOUT;
+        if (rc == SRT_ERR_LAYOUT) {
+            if (pt.scene) { srt_scene_destroy(pt.scene); pt.scene = nullptr; }
+            rc = srt_scene_create(pt.device, &d, &pt.scene);
+            if (rc != SRT_OK) { pt.scene = nullptr; throw std::runtime_error(std::string("srt_scene_create: ") + srt_strerror(rc)); }
+        } else if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_update: ") + srt_strerror(rc));
+        const srt_params p = params_of(k);
+        pt.rows = srt_rows_owned(&p);
+        const size_t bytes = (size_t)pt.rows * W * 3;
+        if (bytes > pt.bytes) {
+            if (pt.rgb8) srt_host_free(pt.rgb8);
+            pt.rgb8 = (uint8_t*)srt_host_alloc(bytes ? bytes : 1);
+            pt.bytes = pt.rgb8 ? bytes : 0;
+            if (!pt.rgb8) throw std::runtime_error("srt_host_alloc failed");
+        }
+        rc = srt_render_async(pt.scene, &p, nullptr, nullptr, nullptr, pt.rgb8);
+        if (rc != SRT_OK) throw std::runtime_error(std::string("srt_render_async: ") + srt_strerror(rc));
+    }
+    frame_.assign((size_t)W * H * 3, 0);
+    for (uint32_t k = 0; k < N; k++) {
+        Part& pt = parts_[k];
+        const int rc = srt_sync(pt.scene, nullptr);
+        if (rc != SRT_OK) throw std::runtime_error(std::string("srt_sync: ") + srt_strerror(rc));
+        for (uint32_t r = 0; r < pt.rows; r++) {                        // local row -> image row (include/srt.h srt_params)
+            const uint32_t y = ((r / blockRows_) * N + k) * blockRows_ + r % blockRows_;
+            std::memcpy(&frame_[(size_t)y * W * 3], pt.rgb8 + (size_t)r * W * 3, (size_t)W * 3);
+        }
+    }
+    return image_data_from_rgb8(frame_.data(), W, H);
+}
+
 ImageData sendRaysAndIntersectPointsColors(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager,
                                            int lightAmount, int device) {
     // one Renderer per thread and device, kept for the life of the thread (leaked on purpose: no HIP calls from thread-exit

@@ -177,6 +177,27 @@ private:
     bool pending_ = false;
 };
 
+// The framebuffer split of several GPUs driven from ONE C++ host process: the scene is replicated (one device scene per entry of
+// `devices`), every frame is dealt in scanline blocks of `blockRows` rows block-cyclically (srt_params.block_rows / block_first /
+// block_stride), each device renders its rows into its own pinned buffer on its own stream -- the devices run concurrently -- and
+// the host puts the rows together.  Results are the single-device results bit for bit (a pixel does not depend on who renders
+// it).  (bench.py's N-GPU path is one process per GPU with one RCCL gather per step; this is the same split for a host program
+// that owns all the GPUs of a node.)
+class MultiRenderer {
+public:
+    explicit MultiRenderer(const std::vector<int>& devices, uint32_t blockRows = 8);
+    ~MultiRenderer();
+    MultiRenderer(const MultiRenderer&) = delete;
+    MultiRenderer& operator=(const MultiRenderer&) = delete;
+    ImageData render(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount = 1);
+    const std::vector<uint8_t>& frame() const { return frame_; }      // H x W x 3 of the last render (black = nothing emitted)
+private:
+    struct Part { int device = 0; srt_scene* scene = nullptr; uint8_t* rgb8 = nullptr; size_t bytes = 0; uint32_t rows = 0; };
+    std::vector<Part> parts_;
+    uint32_t blockRows_;
+    std::vector<uint8_t> frame_;
+};
+
 // drawImage (:461-498) pixel contract: 8-bit RGB, every all-black pixel -> (173,216,230); written as
 // a 24-bit BMP like CImg::save_bmp.  displayImage is not supported (headless).
 void drawImage(const vec2& imgSize, const std::vector<vec2>& imagePoints, const std::vector<vec3>& imageColors,

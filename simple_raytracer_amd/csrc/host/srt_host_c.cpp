@@ -203,4 +203,16 @@ int64_t srth_renderer_render_from_camera(void* r, void* om, uint32_t W, uint32_t
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// MultiRenderer: several devices, one process (the framebuffer split on the C++ host)
+void* srth_multi_new(const int* devices, uint32_t n, uint32_t block_rows) {
+    try { return new MultiRenderer(std::vector<int>(devices, devices + n), block_rows); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void srth_multi_free(void* r) { delete (MultiRenderer*)r; }
+int64_t srth_multi_render(void* r, void* om, uint32_t W, uint32_t H, const float* light4, int light_amount, float* rgb) {
+    try {
+        ImageData d = ((MultiRenderer*)r)->render(vec2((float)W, (float)H), vec4(light4[0], light4[1], light4[2], light4[3]), (ObjectManager*)om, light_amount);
+        return rgb ? image_to_dense(d, W, H, rgb) : (int64_t)d.imagePoints.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
 } // extern "C"

@@ -285,6 +285,37 @@ class Renderer:
                                                                  _p(rgb) if image else None), rgb)
 
 
+class MultiRenderer:
+    """srt_host::MultiRenderer: the framebuffer split over several devices from ONE host process (scene replicated, scanline blocks dealt
+    block-cyclically, rows put together on the host)."""
+
+    def __init__(self, devices, block_rows=8):
+        self.L = load()
+        self.L.srth_multi_new.restype = C.c_void_p
+        self.L.srth_multi_new.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_uint32]
+        self.L.srth_multi_free.argtypes = [C.c_void_p]
+        self.L.srth_multi_render.restype = C.c_int64
+        self.L.srth_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
+        dv = (C.c_int * len(devices))(*devices)
+        self.h = self.L.srth_multi_new(dv, len(devices), block_rows)
+        if not self.h:
+            raise HostError(self.L.srth_last_error().decode())
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.srth_multi_free(self.h); self.h = None
+        except Exception:
+            pass
+
+    def render(self, om, W, H, light4, light_amount=1):
+        light4 = _f(light4); rgb = np.empty((H, W, 3), np.float32)
+        n = self.L.srth_multi_render(self.h, om.om, W, H, _p(light4), light_amount, _p(rgb))
+        if n < 0:
+            raise HostError(self.L.srth_last_error().decode())
+        return rgb, int(n)
+
+
 def sort_keys_both_ways(keys):
     """Test hook: (permutation by the hierarchy builder's parallel sort, permutation by std::sort) of float keys."""
     keys = _f(keys)

@@ -390,6 +390,28 @@ def test_renderer_keeps_the_scene_across_frames(srt, oracle):
         assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2 and n > 1500, angle
 
 
+def test_multi_renderer_splits_the_frame_over_devices(srt):
+    """srt_host::MultiRenderer, the framebuffer split driven from one C++ host process: three device scenes (all on the box's one GPU
+    here -- the split, the concurrent streams and the host-side reassembly are the same), scanline blocks of 8 and of 5 rows, two
+    frames through the same handles (the second updates the device scenes in place).  Equal to the single-device Renderer's frame
+    pixel for pixel."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    cube = gu.load_mesh("cube")
+    W, H = 150, 101                                            # neither a multiple of the tile nor of the blocks
+    one = host.Renderer(0)
+    for block_rows in (8, 5):
+        multi = host.MultiRenderer([0, 0, 0], block_rows=block_rows)
+        for angle in (0.0, 25.0):
+            rec = scenes.four_cubes(T, angle)
+            om = host.ObjectManager(); rec.replay(om, {"cube": cube})
+            light = list(rec.light) + [1.0]
+            a, na = one.render(om, W, H, light, light_amount=3)
+            b, nb = multi.render(om, W, H, light, light_amount=3)
+            assert na == nb and na > 1000 and np.array_equal(a, b), (block_rows, angle)
+
+
 def test_soup_scene_matches_oracle(srt, oracle):
     """Synthetic triangle soup (BASELINE config 5 generator) at a size the oracle finishes in seconds:
     4 objects, cross-object shadows, built by the oracle-side reference-free path."""
