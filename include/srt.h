@@ -171,7 +171,9 @@ int srt_scene_destroy(srt_scene* s);
 /* Another handle on the SAME device records (no copy of the geometry; they are freed with the last handle): its own workspace,
  * counters, statistics and stream, so that several frames of one static scene -- other lights, another camera (ray_matrix),
  * another share of the frame -- can be in flight at once (streams, srt_render_device_batch) while the records stay hot in L2 /
- * Infinity Cache once.  srt_scene_update through any of the handles rewrites the records all of them read. */
+ * Infinity Cache once.  srt_scene_update through any of the handles rewrites the records all of them read; it is ordered on THAT
+ * call's stream only, so the other handles must not have renders in flight and must not render before it has completed (e.g. a
+ * render enqueued behind it on the same stream has been waited for). */
 int srt_scene_share(srt_scene* src, srt_scene** out);
 
 /* The next frame's geometry into the SAME device allocations (the reference re-transforms and rebuilds everything per frame,

@@ -292,6 +292,16 @@ def test_scene_update_reuses_the_device_scene(srt, oracle):
         ds.update(g.flat)                      # other counts
     assert e.value.code == abi.SRT_ERR_LAYOUT
     assert np.array_equal(ds.render(p)["hit_id"], first["hit_id"])        # the refused update changed nothing
+    # handles that share the records (srt_scene_share) see an update made through any of them; the records outlive the first handle
+    twin = ds.share()
+    f7 = frame(7.0)
+    twin.update(f7)                        # ordered on twin's own stream: its render below is behind the copies and waits for them
+    want = srt.DeviceScene(f7).render(p)
+    for h in (twin, ds):
+        o = h.render(p)
+        assert np.array_equal(o["hit_id"], want["hit_id"]) and np.array_equal(o["rgb8"], want["rgb8"])
+    ds.close()
+    assert np.array_equal(twin.render(p)["rgb8"], want["rgb8"])
 
 
 def test_textured_asset_from_files_through_the_loader_to_hip(srt, oracle, tmp_path):
