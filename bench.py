@@ -143,7 +143,7 @@ def measure(args):
     # One handle per frame of a batch, else one per stream.
     split_n = int(args.emulate_split.split("/")[1]) if args.emulate_split else world // max(1, args.frame_groups)
     n_mine = B // max(1, args.frame_groups)
-    batch = (args.batch == "on" or (args.batch == "auto" and split_n > 4)) and 1 <= L <= 7 and args.variant == 0 and args.spp == 1 and n_mine > 1
+    batch = (args.batch == "on" or (args.batch == "auto" and split_n > 4)) and L >= 1 and args.variant == 0 and args.spp == 1 and n_mine > 1
     scenes_ = [lib.DeviceScene(g.flat, device=local_rank)]
     scenes_ += [scenes_[0].share() for _ in range((max(S, n_mine) if batch else S) - 1)]      # the frames of a step render ONE scene: one copy of its records
     scene = scenes_[0]
@@ -184,7 +184,7 @@ def measure(args):
         # next batch) inside the Infinity Cache -- a batch traces all its frames, then shades them.  The batches of a step go
         # to --batch-groups streams in turn (own handles and buffers per stream), so one batch's shading overlaps the next's tracing.
         G = max(1, min(args.batch_groups, S, B))
-        nb = args.batch_frames if args.batch_frames > 0 else max(1, min(B, (256 << 20) // max(1, rows * Wl * 23)))
+        nb = args.batch_frames if args.batch_frames > 0 else max(1, min(B, (512 << 20) // max(1, rows * Wl * 23)))
         nb = min(nb, NB // G)
         starts = list(range(0, B, nb))
         def make(slot, i, a0):

@@ -560,9 +560,11 @@ static int check_params(const srt_params* p) {
 
 // Frames whose launches srt_render_device_batch holds back to issue them as one grid (k_trace_nq_batch + k_shade_tile_batch).
 struct BatchCollector {
-    std::vector<FrameItem> items;
+    std::vector<FrameItem> items;        // frames of the fused pipeline (1..7 light samples): k_trace_nq_batch + k_shade_tile_batch
+    std::vector<FrameItem> items_pk;     // frames of the 8+-sample pipeline: k_closest_hit_nq_batch + k_shadow_pk_batch + k_shade_tile_batch
     uint32_t wl = 0, rows = 0;           // every held frame writes the same local width and row count: one grid fits all
-    bool accepts(uint32_t w, uint32_t r) { if (items.empty()) { wl = w; rows = r; } return w == wl && r == rows; }
+    uint32_t max_lights = 0;
+    bool accepts(uint32_t w, uint32_t r) { if (items.empty() && items_pk.empty()) { wl = w; rows = r; } return w == wl && r == rows; }
 };
 
 static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, int32_t* d_hit_id, float* d_t,
@@ -754,6 +756,14 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+            } else if (bc && !count && (p->flags >> 8 & 0xffu) == 0 && pk_shadow && !pk_closest && spp == 1 && bc->accepts(wl, rows)) {
+                // 8+ light samples, held back: node-queue closest hit, packet shadow kernel and shading of the batch's frames in three launches
+                FrameItem it{s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr, zero_next, s->d_qcount, s->ws_qlist, s->qcap, 0u};
+                it.p.shadow_px_major = 1u;
+                bc->items_pk.push_back(it);
+                if (p->n_lights > bc->max_lights) bc->max_lights = p->n_lights;
+                std::snprintf(s->pipeline, sizeof(s->pipeline), "k_closest_hit_nq+k_shadow_pk+k_shade_tile (batched)");
+                return SRT_OK;
             } else if (!count && coarse_grid) {
                 // 2 x 2 tiles per workgroup (a quarter of the workgroups for frames that are mostly background).  Measured and NOT
                 // shipped: K4 closest hit 0.44 ms against 0.29 with one tile per workgroup, K3 0.22 against 0.10 -- the launch is not
@@ -899,7 +909,32 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
     for (uint32_t i = 0; i < n; i++) {
         const int rc = render_device_impl(scenes[i], &params[i], stream_, d_hit_id ? d_hit_id[i] : nullptr, d_t ? d_t[i] : nullptr,
                                           d_rgb_linear ? d_rgb_linear[i] : nullptr, d_rgb8 ? d_rgb8[i] : nullptr, &bc);
-        if (rc != SRT_OK) { bc.items.clear(); for (uint32_t k = 0; k <= i; k++) scenes[k]->ctr_dirty = true; return rc; }   // held frames are dropped: their counter sets may be half-used
+        if (rc != SRT_OK) { bc.items.clear(); bc.items_pk.clear(); for (uint32_t k = 0; k <= i; k++) scenes[k]->ctr_dirty = true; return rc; }   // held frames are dropped: their counter sets may be half-used
+    }
+    if (!bc.items_pk.empty()) {
+        const size_t held_pk = bc.items_pk.size();
+        const FrameItem* table = nullptr;
+        int rc = frame_table(scenes[0], bc.items_pk, stream, &table);
+        const dim3 block(256), g8((bc.wl + 7) / 8, (bc.rows + 7) / 8, (uint32_t)held_pk), g16((bc.wl + 15) / 16, (bc.rows + 15) / 16, (uint32_t)held_pk);
+        const uint64_t n_tiles = (uint64_t)g8.x * g8.y, max_units = n_tiles * 4u * 2u * ((bc.max_lights + 7) / 8);
+        uint64_t wgs_all = (uint64_t)scenes[0]->n_cu * 8;               // the chip's worth of waves, shared by the frames
+        uint32_t wgs = (uint32_t)((wgs_all + held_pk - 1) / held_pk);
+        if ((uint64_t)wgs > max_units / 4 + 1) wgs = (uint32_t)(max_units / 4 + 1);
+        if (rc == SRT_OK && table) {
+            hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true>), g8, block, 0, stream, table);
+            hipLaunchKernelGGL((k_shadow_pk_batch<true>), dim3(wgs, (uint32_t)held_pk), block, 0, stream, table);
+            hipLaunchKernelGGL(k_shade_tile_batch, g16, block, 0, stream, table);
+            if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
+        } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
+            const uint32_t wgs1 = (uint32_t)(max_units / 4 + 1 < wgs_all ? max_units / 4 + 1 : wgs_all);
+            for (const FrameItem& it : bc.items_pk) {
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true>), dim3(g8.x, g8.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, it.qcount, it.qlist, it.qcap);
+                hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs1), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
+                hipLaunchKernelGGL(k_shade_tile, dim3(g16.x, g16.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+                if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
+            }
+        }
+        if (rc != SRT_OK) { for (uint32_t k = 0; k < n; k++) scenes[k]->ctr_dirty = true; return rc; }
     }
     const size_t held = bc.items.size();
     if (!held) return SRT_OK;

@@ -1256,13 +1256,32 @@ __global__ __launch_bounds__(256, MINW) void k_trace_shade_nq(DevScene s, DevPar
 // launch lasts a whole number of such rounds.  The 1080p frame has ~2,500 heavy tiles (1.6 rounds in 0.125 ms); the eighth of it
 // that one of eight GPUs owns has ~310 and still takes 0.072 ms as its own launch, nine eighths launched together take 0.199 ms
 // (two rounds) where 0.142 would be their share -- measured with tools/strip_probe.py, whatever the height of the scanline blocks.
-// With ALL frames of a step in one grid the rounds are filled.  A frame's arguments come from a table in device memory (352 bytes
+// With ALL frames of a step in one grid the rounds are filled.  A frame's arguments come from a table in device memory (368 bytes
 // a frame; the kernarg segment's 4 KiB would hold ten), read with scalar loads: the index is blockIdx.z, the table is read-only.
 struct FrameItem {
     DevScene s; DevParams p;
     int32_t* hit_id; float* t_out; float* rgb_linear; uint8_t* rgb8;
     unsigned long long* shadow_bits; unsigned long long* counters; unsigned long long* counters_next; uint32_t* qcount;
+    uint32_t* qlist; uint32_t qcap, pad_;      // the frame's quadrant list (8+-sample pipeline)
 };
+// the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)
+template <int NQCAP, bool FILTER>
+__global__ __launch_bounds__(256) void k_closest_hit_nq_batch(const FrameItem* __restrict__ items) {
+    const FrameItem it = items[blockIdx.z];
+    __shared__ uint32_t nq_all[4][NQCAP];
+    __shared__ uint32_t tq_all[4][LQ_WORDS];
+    __shared__ unsigned long long best_all[4][NQ_P];
+    __shared__ float4 dir_all[4][NQ_P];
+    __shared__ uint32_t root_pass[64];
+    const uint32_t wave = threadIdx.x >> 6;
+    int32_t id; float t; V3 d;
+    const bool roots_done = it.s.n_objects <= 32u;
+    if (finish_background_tile<FILTER>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
+    closest_hit_phase<false, NQCAP, 2, 2, FILTER>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                  it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave,
+                                                  it.qcount, it.qlist, it.qcap, roots_done ? root_pass + wave * 16 : nullptr);
+}
+
 template <int NQCAP, bool FILTER, int MINW, int RS>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameItem* __restrict__ items) {
     const FrameItem it = items[blockIdx.z];

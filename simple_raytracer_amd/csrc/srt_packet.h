@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
 // =================================================================================================
 // qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) units handed out per fetch shard; counters
 // QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
-template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false>
-__global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
-                                                   uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
-                                                   unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
-    __shared__ PkWindows win_all[4];
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR>
+__device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParams& p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
+                                               uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
+                                               unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
+    __shared__ PkWindows win_all[WINDOWS ? 4 : 1];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t nbase = 0x80000000u, tbase = 0x80000000u;                   // window bases (sentinel: nothing loaded); the windows outlive a walk
     const uint32_t tiles_x = (p.W + 7u) / 8u;
@@ -388,4 +388,17 @@ __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, 
         // shape of the packet walks (read by srt_sync into the SRT_DIAG_COUNTERS dump): uniform values, lane 0 adds
         if (lane == 0) { atomicAdd(counters + 5, diag[0]); atomicAdd(counters + 6, diag[1]); atomicAdd(counters + 7, diag[2]); atomicAdd(counters + 0, diag[4]); }
     }
+}
+
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false>
+__global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
+                                                   uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
+                                                   unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
+    shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
+}
+// the frames of a batch (srt_render_device_batch): blockIdx.y = frame, gridDim.x waves-of-four pull the units of THAT frame's list
+template <bool FILTER>
+__global__ __launch_bounds__(256, 8) void k_shadow_pk_batch(const FrameItem* __restrict__ items) {
+    const FrameItem it = items[blockIdx.y];
+    shadow_pk_body<false, FILTER, false, false>(it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
 }

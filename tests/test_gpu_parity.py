@@ -144,8 +144,9 @@ def test_tiles_dealt_in_two_dimensions_reassemble_bitwise(srt, name, W, H, L):
 
 
 def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
-    """srt_render_device_batch: 14 frames (two scenes, different lights, a scanline-block share, and three frames that cannot share
-    a launch: 9 light samples, another size, the counting build) come out bit for bit as 14 srt_render calls do, and every
+    """srt_render_device_batch: 17 frames (two scenes, different lights, a scanline-block share; eleven of the fused pipeline and
+    three of the 8+-sample pipeline share launches; three cannot: another size twice, the counting build) come out bit for bit as
+    17 srt_render calls do, and every
     handle's statistics are its own frame's.  (Output buffers: pinned host memory from srt_host_alloc, which the device addresses
     directly -- no second HIP user in the test process.)"""
     import ctypes as C
@@ -165,9 +166,11 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
         g = ga if k % 3 else gb
         light = g.light.copy(); light[0] += 40.0 * k
         frames.append((g, abi.make_params(W, H, abi.light_staircase(light, 1 + k % 3), block_rows=8, block_first=1, block_stride=3)))
-    frames.append((ga, ga.params(W, H, 9)))                                     # packet shadow pipeline: launched on its own
+    frames.append((ga, ga.params(W, H, 9)))                                     # packet shadow pipeline at another size: launched on its own
     frames.append((gb, gb.params(128, 96, 2)))                                  # fused, but another size: second group
     frames.append((ga, abi.make_params(W, H, abi.light_staircase(ga.light, 2), block_rows=8, block_first=1, block_stride=3, flags=abi.SRT_FLAG_COUNT_WORK)))
+    for L in (9, 12, 64):                                                       # 8+ samples at the common size: the second shared group (three launches)
+        frames.append((ga if L != 12 else gb, abi.make_params(W, H, abi.light_staircase(ga.light, L), block_rows=8, block_first=1, block_stride=3)))
     # frames of the same scene share ONE copy of its device records (srt_scene_share); the handle that uploaded them goes first
     first = {id(ga): srt.DeviceScene(ga.flat), id(gb): srt.DeviceScene(gb.flat)}
     handles = [first[id(g)].share() for g, _ in frames]
@@ -193,7 +196,8 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
             for key in ("hit_rays", "shadow_rays", "primary_rays", "rows", "node_tests", "tri_tests"):
                 assert st[key] == o["stats"][key], (k, key)
             one.close()
-    assert handles[0].pipeline == "k_trace_nq+k_shade_tile (batched)" and "k_shadow_pk" in handles[11].pipeline
+    assert handles[0].pipeline == "k_trace_nq+k_shade_tile (batched)" and handles[11].pipeline == "k_closest_hit_nq+k_shadow_pk+k_shade_tile"
+    assert handles[14].pipeline == handles[16].pipeline == "k_closest_hit_nq+k_shadow_pk+k_shade_tile (batched)"
     # a handle twice in one call: refused before anything is enqueued
     with pytest.raises(srt.SrtError) as e:
         srt.FrameBatch([handles[0], handles[0]], [frames[0][1]] * 2).render()
