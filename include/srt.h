@@ -195,16 +195,17 @@ int srt_scene_update(srt_scene* s, const srt_scene_desc* desc, void* stream);
 int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
                       int32_t* d_hit_id, float* d_t, float* d_rgb_linear, uint8_t* d_rgb8);
 
-/* The frames of a step (the reference's main() renders a 36-frame orbit, simple_raytracer.cpp:534) in ONE pair of launches:
+/* The frames of a step (the reference's main() renders a 36-frame orbit, simple_raytracer.cpp:534) in ONE set of launches:
  * frame i = srt_render_device(scenes[i], &params[i], stream, d_hit_id[i], ...), with bitwise the same outputs.  The handles must
- * be n DISTINCT scenes on one device (a handle's workspace serves one frame at a time; the same geometry may be created n
- * times); each output table may be NULL, and so may its entries.  Frames that take the default pipeline for 1..7 light samples
- * at one common size share the launches, which fills the chip where one frame -- or the eighth of it one of eight GPUs owns --
- * does not (a silhouette tile occupies its workgroup for the better part of such a launch); any other frame is launched on its
- * own as srt_render_device would.  The frames' arguments go to device memory once per distinct batch (kept on scenes[0], 128
- * batches remembered; a handle's counter sets alternate, so a repeated call has two).  That takes blocking calls: a batch first
- * seen while `stream` is capturing is launched frame by frame -- issue it twice before the capture.  No per-frame times: srt_sync()'s ms_* keep
- * the values of the last timed render of each handle. */
+ * be n DISTINCT handles on one device (a handle's workspace serves one frame at a time; srt_scene_share gives n handles on one
+ * copy of a scene); each output table may be NULL, and so may its entries.  Frames that take the default pipeline at one common
+ * size share the launches -- those with 1..7 light samples one pair of launches, those with 8 and more three -- which fills the
+ * chip where one frame, or the eighth of it one of eight GPUs owns, does not (a silhouette tile occupies its workgroup for the
+ * better part of such a launch); any other frame is launched on its own as srt_render_device would.  The frames' arguments go
+ * to device memory once per distinct batch (kept on scenes[0], 128 batches remembered; a handle's counter sets alternate, so a
+ * repeated call has two).  That takes blocking calls: a batch first seen while `stream` is capturing is launched frame by frame
+ * -- issue it twice before the capture.  No per-frame times: srt_sync()'s ms_* keep the values of the last timed render of each
+ * handle. */
 int srt_render_device_batch(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream,
                             int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8);
 
