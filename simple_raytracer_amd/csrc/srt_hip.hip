@@ -903,6 +903,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         for (uint32_t k = 0; k < i; k++) if (scenes[k] == scenes[i]) return SRT_ERR_ARG;      // a handle's workspace serves one frame at a time
         const int rc = check_params(&params[i]);                                               // nothing is enqueued if any frame is malformed
         if (rc != SRT_OK) return rc;
+        if ((params[i].flags & SRT_FLAG_SMOOTH_NORMALS) && (!scenes[i]->dev.tri_normals || variant_of(&params[i]) == 1)) return SRT_ERR_ARG;
     }
     hipStream_t stream = (hipStream_t)stream_;
     BatchCollector bc;
