@@ -898,6 +898,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
                                     int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8) {
     if (!n) return SRT_OK;
     if (!scenes || !params) return SRT_ERR_ARG;
+    if (n > 65535u) return SRT_ERR_LIMIT;                     // the frame is a grid dimension
     for (uint32_t i = 0; i < n; i++) {
         if (!scenes[i] || scenes[i]->device != scenes[0]->device) return SRT_ERR_ARG;
         for (uint32_t k = 0; k < i; k++) if (scenes[k] == scenes[i]) return SRT_ERR_ARG;      // a handle's workspace serves one frame at a time
