@@ -1011,8 +1011,13 @@ FlatScene flattenScene(ObjectManager* om) {
 // ------------------------------------------------------------------------------------------------
 // hit pixels of an 8-bit frame in the reference's emission order: x outer, y inner (:511-513).  Count per column, then fill the
 // slots in parallel.  Black = "not emitted" (:518).
-static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t H) {
-    ImageData out;
+// `out` may come pre-sized (Renderer::collect sizes it by the previous frame's count while the GPU is still rendering: resize
+// value-initialises, 20 bytes per emitted pixel of zero fill that then costs nothing on the critical path).
+static void resize_both(ImageData& out, size_t n) {
+    parallel_for(2, 1, [&](size_t b, size_t e) { for (size_t k = b; k < e; k++) { if (k == 0) out.imagePoints.resize(n); else out.imageColors.resize(n); } });
+}
+static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t H, ImageData&& pre = ImageData()) {
+    ImageData out = std::move(pre);
     std::vector<size_t> col(W + 1, 0);
     parallel_for(W, 64, [&](size_t x0, size_t x1) {
         for (size_t x = x0; x < x1; x++) {
@@ -1022,8 +1027,7 @@ static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t 
         }
     });
     for (uint32_t x = 0; x < W; x++) col[x + 1] += col[x];
-    // (resize value-initialises: 20 bytes per emitted pixel of serial zero fill -- the two vectors on two threads)
-    parallel_for(2, 1, [&](size_t b, size_t e) { for (size_t k = b; k < e; k++) { if (k == 0) out.imagePoints.resize(col[W]); else out.imageColors.resize(col[W]); } });
+    if (out.imagePoints.size() < col[W] || out.imageColors.size() < col[W]) resize_both(out, col[W]);      // first frame, or more pixels than guessed
     parallel_for(W, 64, [&](size_t x0, size_t x1) {
         for (size_t x = x0; x < x1; x++) {
             size_t k = col[x];
@@ -1037,6 +1041,7 @@ static ImageData image_data_from_rgb8(const uint8_t* rgb8, uint32_t W, uint32_t 
             }
         }
     });
+    if (out.imagePoints.size() != col[W]) { out.imagePoints.resize(col[W]); out.imageColors.resize(col[W]); }      // shrinking: no fill
     return out;
 }
 
@@ -1090,9 +1095,13 @@ void Renderer::submit(const vec2& imageSize, const vec4& lightPos, ObjectManager
 ImageData Renderer::collect() {
     if (!pending_) throw std::runtime_error("Renderer::collect: nothing submitted");
     pending_ = false;
+    ImageData pre;
+    if (last_count_) resize_both(pre, last_count_ + last_count_ / 16 + 64);      // while the GPU renders: the zero fill of the result vectors
     const int rc = srt_sync(scene_, nullptr);
     if (rc != SRT_OK) throw std::runtime_error(std::string("srt_sync: ") + srt_strerror(rc));
-    return image_data_from_rgb8(rgb8_, W_, H_);
+    ImageData out = image_data_from_rgb8(rgb8_, W_, H_, std::move(pre));
+    last_count_ = out.imagePoints.size();
+    return out;
 }
 
 ImageData Renderer::render(const vec2& imageSize, const vec4& lightPos, ObjectManager* objManager, int lightAmount) {

@@ -175,6 +175,7 @@ private:
     uint8_t* rgb8_ = nullptr; size_t rgb8_bytes_ = 0;      // pinned
     uint32_t W_ = 0, H_ = 0;
     bool pending_ = false;
+    size_t last_count_ = 0;          // pixels the previous frame emitted: the next frame's ImageData is sized by it while the GPU renders
 };
 
 // The framebuffer split of several GPUs driven from ONE C++ host process: the scene is replicated (one device scene per entry of
