@@ -56,6 +56,7 @@ def parse_args():
                     help="HIP streams the frames of a step are spread over (each with its own scene handle and buffers, one copy of the scene's "
                          "records).  Default 4: one frame's shading overlaps the next frame's tracing.  The per-kernel durations of the "
                          "roofline block are measured on eager launches on ONE stream either way; profile with --streams 1 to see kernels alone")
+    ap.add_argument("--block-rows", type=int, default=BLOCK_ROWS, help="rows per scanline block of the N-way split (a multiple of 8)")
     ap.add_argument("--batch-groups", type=int, default=1, help="with --batch: the batches of a step go to this many streams in turn")
     ap.add_argument("--batch-frames", type=int, default=0, help="with --batch: frames per srt_render_device_batch call (0 = as many as keep the intermediates in cache)")
     ap.add_argument("--batch", choices=["auto", "on", "off"], default="auto",
@@ -122,6 +123,8 @@ def setup(args):
 
 def measure(args):
     """One workload, measured as the contract says.  Returns the JSON object on rank 0, None elsewhere."""
+    global BLOCK_ROWS
+    BLOCK_ROWS = args.block_rows
     import torch
     import torch.distributed as dist
     from simple_raytracer_amd import abi, lib
