@@ -18,6 +18,9 @@ def recipe(parts):
         r.load("./obj/stanford-bunny.obj", "bunny"); r.color("./obj/stanford-bunny.obj", (0.9, 0.9, 0.9))
         r.transform("./obj/stanford-bunny.obj", MM.scale(1500.0, 1500.0, 1500.0)); r.transform("./obj/stanford-bunny.obj", MM.rotx(MM.radians(180.0)))
         r.transform("./obj/stanford-bunny.obj", MM.translate(20.0, 170.0, 300.0)); r.bvh("./obj/stanford-bunny.obj")
+    if "far" in parts:                                 # a cube no ray can reach: a frame of background tiles only
+        r.load("cube.obj", "cube"); r.color("cube.obj", (0.2, 0.7, 0.3))
+        r.transform("cube.obj", MM.translate(0.0, 50000.0, 350.0)); r.bvh("cube.obj")
     if "slab" in parts:
         r.load("cube.obj", "cube"); r.color("cube.obj", (0.2, 0.7, 0.3))
         r.transform("cube.obj", MM.scale(400.0, 10.0, 400.0)); r.transform("cube.obj", MM.translate(0.0, 130.0, 350.0)); r.bvh("cube.obj")
@@ -29,7 +32,7 @@ def main():
     import torch
     W, H = 1920, 1080
     meshes = {"bunny": gu.load_mesh("bunny"), "cube": gu.load_mesh("cube")}
-    for parts in (("bunny", "slab"), ("slab",), ("bunny",)):
+    for parts in (("bunny", "slab"), ("slab",), ("bunny",), ("far",)):
         r = recipe(parts)
         flat = host.build_flat_scene(r, {k: meshes[k] for k in r.meshes})
         p = abi.make_params(W, H, abi.light_staircase(np.array(r.light, np.float32), 1))
@@ -42,6 +45,7 @@ def main():
         st = hs[0].sync()
         pc = abi.make_params(W, H, abi.light_staircase(np.array(r.light, np.float32), 1), flags=abi.SRT_FLAG_COUNT_WORK)
         hs[0].render_device(pc); sc = hs[0].sync()
+        sc.setdefault('hit_rays', 0)
         streams = [torch.cuda.Stream() for _ in range(4)]
         pq = abi.make_params(W, H, abi.light_staircase(np.array(r.light, np.float32), 1), flags=abi.SRT_FLAG_NO_TIMING)
         def frames(n):
