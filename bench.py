@@ -287,6 +287,12 @@ def measure(args):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # N > 1: what rank 0 holds after the last gather must be the frame one GPU renders (every step renders the same frames)
+    gathered_ok = None
+    if world > 1 and rank == 0 and FG == 1 and gather.frame is not None:
+        whole = lib.DeviceScene(g.flat, device=local_rank).render(abi.make_params(W, H, lights, spp=args.spp), want=("rgb8",))["rgb8"]
+        got = gather.frame.cpu().numpy()
+        gathered_ok = bool(all(np.array_equal(got[f], whole) for f in (0, got.shape[0] - 1)))
     # per-kernel durations: HIP events on the launch stream over B eager renders of the same frames (the events of
     # a captured graph cannot be read back), averaged by srt_sync
     for sc_ in scenes_:
@@ -365,6 +371,7 @@ def measure(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
+            **({"gathered_frames_equal_one_gpu_render": gathered_ok} if gathered_ok is not None else {}),
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
                        else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
