@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU: small scenes of many shapes (few big objects, many small ones, cubes, slivers, shared triangles),
+random frame sizes, light-sample counts 1..12, whole frames and scanline-block shares -- the SHIPPED (non-counting) pipelines
+against the CPU oracle: hit ids and t bit for bit, linear colour within the tolerance, rgb8 within 1 LSB on a bounded number of
+pixels; and the batch call against the single renders.  Usage (GPU box): python tools/fuzz_gpu.py [--seeds 40] [--first 0]"""
+import argparse, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from simple_raytracer_amd import abi, host, lib      # noqa: E402
+from oracle import pyoracle                          # noqa: E402
+import golden_util as gu                             # noqa: E402
+import scenes                                        # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def random_scene(rng, cube):
+    recipe = scenes.Recipe(); meshes = {"cube": cube}
+    T = host.Transformation
+    n_obj = int(rng.integers(1, 9))
+    for k in range(n_obj):
+        kind = rng.integers(0, 3)
+        name = f"obj{k}"
+        if kind == 0:                                  # a transformed cube (root + two leaves): the ground of the reference's scenes
+            recipe.load(name, "cube")
+            recipe.transform(name, T.scaleObj(*[float(x) for x in rng.uniform(5, 300, 3)]))
+            recipe.transform(name, T.rotateObjY(T.radians(float(rng.uniform(0, 90)))))
+            recipe.transform(name, T.changeObjPosition(float(rng.uniform(-150, 150)), float(rng.uniform(-100, 150)), float(rng.uniform(200, 600))))
+        else:                                          # a soup of n triangles, some of them big
+            n = int(rng.integers(1, 400 if kind == 1 else 40))
+            c = rng.uniform(-150, 150, (n, 1, 3)); c[..., 2] += 380
+            pts = np.ones((n, 3, 4), np.float32)
+            pts[..., :3] = c + rng.uniform(-1, 1, (n, 3, 3)) * rng.choice([3.0, 25.0, 120.0])
+            meshes[f"m{k}"] = pts
+            recipe.load(name, f"m{k}")
+        recipe.color(name, rng.uniform(0, 1, 3)); recipe.bvh(name)
+    recipe.light = tuple(float(x) for x in rng.uniform(-500, 500, 3))
+    return recipe, meshes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--first", type=int, default=0)
+    a = ap.parse_args()
+    pyoracle.oracle_lib()
+    cube = gu.load_mesh("cube")
+    bad = 0
+    for seed in range(a.first, a.first + a.seeds):
+        rng = np.random.default_rng(1000 + seed)
+        recipe, meshes = random_scene(rng, cube)
+        flat = host.build_flat_scene(recipe, meshes)
+        W, H = int(rng.integers(17, 200)), int(rng.integers(9, 150))
+        L = int(rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 12]))
+        lights = abi.light_staircase(recipe.light, L)
+        kw = {}
+        if rng.random() < 0.5:
+            stride = int(rng.integers(2, 5)); kw = dict(block_rows=8 * int(rng.integers(1, 3)), block_first=int(rng.integers(0, stride)), block_stride=stride)
+        p = abi.make_params(W, H, lights, **kw)
+        ds = lib.DeviceScene(flat)
+        if ds.rows(p) == 0:
+            continue
+        o = ds.render(p)
+        c = pyoracle.render(flat, p)
+        ok = np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+        fin = np.isfinite(c["rgb_linear"]).all(-1)
+        tol = 1e-4 * max(1.0, float(np.abs(c["rgb_linear"][fin]).max())) if fin.any() else 1e-4
+        ok = ok and (not fin.any() or float(np.abs(o["rgb_linear"][fin] - c["rgb_linear"][fin]).max()) < tol)
+        d8 = np.abs(o["rgb8"].astype(np.int32) - c["rgb8"].astype(np.int32))
+        ok = ok and d8.max() <= 1 and int((d8.max(-1) > 0).sum()) <= max(2, W * H // 2000)
+        # the batch call: this frame and a second one with the light moved, on shared records, against the single renders
+        twin = ds.share()
+        light2 = np.asarray(recipe.light, np.float32) + np.float32(17.0)
+        p2 = abi.make_params(W, H, abi.light_staircase(light2, L), **kw)
+        hits = [np.full(o["hit_id"].shape, -9, np.int32) for _ in range(2)]
+        hp = [lib.load().srt_host_alloc(h.nbytes) for h in hits]
+        import ctypes as C
+        views = [np.frombuffer((C.c_uint8 * hits[k].nbytes).from_address(hp[k]), dtype=np.int32).reshape(hits[k].shape) for k in range(2)]
+        lib.FrameBatch([ds, twin], [p, p2], hp).render()
+        ds.sync(); twin.sync()
+        o2 = lib.DeviceScene(flat).render(p2)
+        ok = ok and np.array_equal(views[0], o["hit_id"]) and np.array_equal(views[1], o2["hit_id"])
+        for x in hp:
+            lib.load().srt_host_free(x)
+        print(f"seed {seed:3d}: {len(flat.names)} objects, {flat.tri_points.shape[0]:5d} triangles, {W}x{H}, L={L:2d}, {kw or 'whole'}: "
+              f"{ds.pipeline:45s} hits {int((c['hit_id'] >= 0).sum()):6d}  {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += 0 if ok else 1
+    print(f"fuzz: {bad} mismatching configuration(s)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
