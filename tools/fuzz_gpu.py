@@ -59,6 +59,8 @@ def main():
         kw = {}
         if rng.random() < 0.5:
             stride = int(rng.integers(2, 5)); kw = dict(block_rows=8 * int(rng.integers(1, 3)), block_first=int(rng.integers(0, stride)), block_stride=stride)
+        if rng.random() < 0.25:                        # camera mode (extension): the rays are taken into the scene's space by a view matrix
+            kw["ray_matrix"] = scenes.orbit_view_matrix(host.Transformation, float(rng.uniform(0, 60)), float(rng.uniform(-40, 40)), float(rng.uniform(-30, 30)), float(rng.uniform(-10, 10)))
         p = abi.make_params(W, H, lights, **kw)
         ds = lib.DeviceScene(flat)
         if ds.rows(p) == 0:
@@ -85,7 +87,7 @@ def main():
         ok = ok and np.array_equal(views[0], o["hit_id"]) and np.array_equal(views[1], o2["hit_id"])
         for x in hp:
             lib.load().srt_host_free(x)
-        print(f"seed {seed:3d}: {len(flat.names)} objects, {flat.tri_points.shape[0]:5d} triangles, {W}x{H}, L={L:2d}, {kw or 'whole'}: "
+        print(f"seed {seed:3d}: {len(flat.names)} objects, {flat.tri_points.shape[0]:5d} triangles, {W}x{H}, L={L:2d}, {({k: v for k, v in kw.items() if k != 'ray_matrix'} or 'whole')}{' camera' if 'ray_matrix' in kw else ''}: "
               f"{ds.pipeline:45s} hits {int((c['hit_id'] >= 0).sum()):6d}  {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += 0 if ok else 1
     print(f"fuzz: {bad} mismatching configuration(s)")
