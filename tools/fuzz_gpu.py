@@ -17,14 +17,20 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def random_scene(rng, cube):
+def random_scene(rng, cube, bunny):
     recipe = scenes.Recipe(); meshes = {"cube": cube}
     T = host.Transformation
     n_obj = int(rng.integers(1, 9))
     for k in range(n_obj):
-        kind = rng.integers(0, 3)
+        kind = rng.integers(0, 4)
         name = f"obj{k}"
-        if kind == 0:                                  # a transformed cube (root + two leaves): the ground of the reference's scenes
+        if kind == 3:                                  # a piece of the bunny: a deep tree of small triangles
+            n = int(rng.integers(200, 6000))
+            meshes[f"m{k}"] = bunny[int(rng.integers(0, bunny.shape[0] - n)):][:n]
+            recipe.load(name, f"m{k}")
+            recipe.transform(name, T.scaleObj(1500.0, 1500.0, 1500.0)); recipe.transform(name, T.rotateObjX(T.radians(180.0)))
+            recipe.transform(name, T.changeObjPosition(float(rng.uniform(-80, 80)), float(rng.uniform(100, 220)), float(rng.uniform(250, 400))))
+        elif kind == 0:                                  # a transformed cube (root + two leaves): the ground of the reference's scenes
             recipe.load(name, "cube")
             recipe.transform(name, T.scaleObj(*[float(x) for x in rng.uniform(5, 300, 3)]))
             recipe.transform(name, T.rotateObjY(T.radians(float(rng.uniform(0, 90)))))
@@ -47,14 +53,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     a = ap.parse_args()
     pyoracle.oracle_lib()
-    cube = gu.load_mesh("cube")
+    cube = gu.load_mesh("cube"); bunny = gu.load_mesh("bunny")
     bad = 0
     for seed in range(a.first, a.first + a.seeds):
         rng = np.random.default_rng(1000 + seed)
-        recipe, meshes = random_scene(rng, cube)
+        recipe, meshes = random_scene(rng, cube, bunny)
         flat = host.build_flat_scene(recipe, meshes)
         W, H = int(rng.integers(17, 200)), int(rng.integers(9, 150))
-        L = int(rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 12]))
+        L = int(rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 12, 20, 64, 70]))
         lights = abi.light_staircase(recipe.light, L)
         kw = {}
         if rng.random() < 0.5:
