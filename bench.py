@@ -412,7 +412,7 @@ def main():
     if args.workload == "ground_bunny" and not args.no_soup and not args.emulate_split and args.spp == 1 and args.variant == 0:
         # north_star's scaling curve is quoted on the synthetic soup: same resolution, same split, a short run
         a2 = copy.copy(args)
-        a2.workload, a2.frames, a2.steps, a2.warmup, a2.lights = "soup", 2, 3, 1, 1
+        a2.workload, a2.frames, a2.steps, a2.warmup, a2.lights = "soup", 4, 3, 1, 1      # 4 frames: one per stream
         a2.no_cpu_baseline = a2.no_pmc = a2.no_parity = True
         o2 = measure(a2)
         if rank == 0:
