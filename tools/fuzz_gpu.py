@@ -22,9 +22,18 @@ def random_scene(rng, cube, bunny):
     T = host.Transformation
     n_obj = int(rng.integers(1, 9))
     for k in range(n_obj):
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 5)
         name = f"obj{k}"
-        if kind == 3:                                  # a piece of the bunny: a deep tree of small triangles
+        if kind == 4:                                  # a textured soup: per-vertex integer texel coordinates into a random image
+            n = int(rng.integers(1, 120))
+            c = rng.uniform(-150, 150, (n, 1, 3)); c[..., 2] += 380
+            pts = np.ones((n, 3, 4), np.float32)
+            pts[..., :3] = c + rng.uniform(-1, 1, (n, 3, 3)) * rng.choice([25.0, 120.0])
+            tw, th = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+            tcs = np.stack([rng.integers(0, tw, (n, 3)), rng.integers(0, th, (n, 3))], -1).reshape(n, 6).astype(np.float32)
+            meshes[f"m{k}"] = {"points": pts, "texcoord": tcs, "texture_name": f"tex{k}.png", "texture": rng.integers(0, 256, (th, tw, 3), dtype=np.uint8)}
+            recipe.load(name, f"m{k}")
+        elif kind == 3:                                  # a piece of the bunny: a deep tree of small triangles
             n = int(rng.integers(200, 6000))
             meshes[f"m{k}"] = bunny[int(rng.integers(0, bunny.shape[0] - n)):][:n]
             recipe.load(name, f"m{k}")
