@@ -364,6 +364,18 @@ def measure(args):
         if pmc is None and world == 1:
             pmc = committed_pmc(args.workload, dom, W, H, L)
         roof = roofline_block(dom, dom_ms, kern[dom]["bytes"], effective, pmc, g)
+        pk = (pmc or {}).get("per_kernel") or {}
+        if roof.get("valu") and pk and args.spp == 1 and all("SQ_INSTS_VALU" in v for v in pk.values()):
+            # the same counters against the TIMED region: the frame's VALU wave-instructions (all kernels of the pipeline, per launch =
+            # per frame) over the cycles a frame takes there, frames overlapped on S streams
+            insts_f = sum(v["SQ_INSTS_VALU"] for v in pk.values())
+            lanes_f = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in pk.values()) / insts_f if insts_f else 0.0
+            cyc_f = (ms_step / B_total) * 1e-3 * roof["valu"]["clock_GHz"] * 1e9
+            issue_f = insts_f * 4.0 / (1024.0 * cyc_f) if cyc_f else 0.0
+            roof["timed_region"] = {"valu_issue_frac": round(min(issue_f, 1.0), 4), "lanes_active_of_64": round(lanes_f, 1),
+                                    "frac_of_lane_peak": round(min(issue_f, 1.0) * lanes_f / 64.0, 4), "kernels": sorted(pk),
+                                    "note": "VALU wave-instructions of ALL kernels of a frame (counters of the kernels running alone) x 4 / (1024 SIMDs x the cycles a frame "
+                                            "takes in the timed region): what the overlap of frames on streams adds to the single kernel's `frac`"}
         roof["kernel_ms_note"] = ("HIP events around eager launches on ONE stream (the kernel running alone, as in profiles/*_kernel_stats.csv and the --pmc "
                                   f"passes); the timed region overlaps the frames of a step on {S} stream(s), where a per-kernel duration is not defined")
         out = {
@@ -465,7 +477,7 @@ def collect_pmc(argv, kernel):
         keep.append(a)
     child = ["python3", os.path.join(ROOT, "bench.py")] + keep + ["--steps", "2", "--warmup", "1", "--frames", "4", "--streams", "1",       # one stream: the counters of a kernel that runs alone
                                                               "--no-cpu-baseline", "--no-pmc", "--no-parity", "--no-soup"]
-    vals, durs = {}, []
+    vals, durs, per_kernel = {}, [], {}
     tmp = tempfile.mkdtemp(prefix="srt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     t0 = time.perf_counter()
@@ -477,14 +489,20 @@ def collect_pmc(argv, kernel):
             if r.returncode:
                 print(f"bench: rocprofv3 pass {grp} failed (rc {r.returncode}); using profiles/traffic.json", file=sys.stderr)
                 return None
-            acc = {}
+            acc, acc_all = {}, {}
             for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
                     nm = row["Kernel_Name"].replace("void ", "")
-                    if nm.startswith(kernel) and "<true" not in nm:          # not the counting build
+                    if "<true" in nm:                                        # the counting build
+                        continue
+                    if nm.startswith(kernel):
                         acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    if nm.startswith("k_") and row["Counter_Name"] in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU"):
+                        acc_all.setdefault((nm.split("<")[0].split("(")[0], row["Counter_Name"]), []).append(float(row["Counter_Value"]))
             for c, v in acc.items():
                 vals[c] = sum(v) / len(v)
+            for (kn, c), v in acc_all.items():
+                per_kernel.setdefault(kn, {})[c] = sum(v) / len(v)
             if i == 0:
                 for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
                     for row in csv.DictReader(open(f)):
@@ -500,7 +518,7 @@ def collect_pmc(argv, kernel):
     if any(k not in vals for k in need):
         return None
     return {"source": f"rocprofv3 --pmc child passes of this run ({time.perf_counter() - t0:.0f} s, {len(durs)} launches)", "counters": vals,
-            "kernel_ms_under_profiler": sum(durs) / len(durs) if durs else None}
+            "kernel_ms_under_profiler": sum(durs) / len(durs) if durs else None, "per_kernel": per_kernel}
 
 
 def committed_pmc(workload, kernel, W, H, L):
