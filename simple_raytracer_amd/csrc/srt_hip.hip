@@ -647,7 +647,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
     const bool coarse_grid = variant == 27;                // 27: variant 0 with 2 x 2 tiles per workgroup in the unfused closest-hit launch (A/B, not shipped)
-    if (force_nq || variant == 25 || variant == 29 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -714,7 +714,10 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         //   nq chunked   the round-1 form for 8+ samples (k_shadow_nq, 64 rays in flight, samples cut over blockIdx.z): variant 20
         // camera mode (rays that do not start at the origin): closest hit on the packet kernel, which takes a general ray; the shadow
         // kernels start from the hit point either way
-        const bool pk_closest = fp.cam || variant == 22 || variant == 23 || (variant == 0 && s->rec->prefer_packet && !force_nq);
+        // camera mode: the fused node-queue kernel has a build for rays with an origin (1..7 samples, variant 0); everything else
+        // in camera mode goes through the packet closest-hit kernel, which takes a general ray
+        const bool cam_nq = fp.cam && variant == 0 && !count && !s->rec->prefer_packet && p->n_lights >= 1 && p->n_lights < 8 && !fp.xcd_rows && (p->flags >> 8 & 0xffu) != 35;
+        const bool pk_closest = (fp.cam && !cam_nq) || variant == 22 || variant == 23 || (variant == 0 && s->rec->prefer_packet && !force_nq);
         const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
@@ -741,7 +744,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (count)       hipLaunchKernelGGL((k_closest_hit_pk<true, true, false>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else if (fp.xcd_rows) hipLaunchKernelGGL((k_closest_hit_pk<false, true, true>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
                 else                  hipLaunchKernelGGL((k_closest_hit_pk<false, true, false>), gp, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ql_cnt, ql, s->qcap, ctr);
-            } else if (fused && bc && !count && (p->flags >> 8 & 0xffu) == 0 && !fp.xcd_rows && spp == 1 && bc->accepts(wl, rows)) {
+            } else if (fused && bc && !count && (p->flags >> 8 & 0xffu) == 0 && !fp.xcd_rows && !fp.cam && spp == 1 && bc->accepts(wl, rows)) {
                 // held back: the batch call launches this frame together with the others (same kernels, same arguments)
                 bc->items.push_back(FrameItem{s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr, zero_next, s->d_qcount});
                 std::snprintf(s->pipeline, sizeof(s->pipeline), "k_trace_nq+k_shade_tile (batched)");
@@ -749,6 +752,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             } else if (fused && variant == 28 && !count && !fp.xcd_rows && p->n_lights < 64) {      // 28 (A/B): the whole frame in one launch
                 hipLaunchKernelGGL((k_trace_shade_nq<512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, zero_next, s->d_qcount);
                 shaded = true;
+            } else if (fused && cam_nq) {      // camera mode on the node queues
+                hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16, false, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else if (fused) {        // closest hit + shadow rays in one launch
                 if (count)              hipLaunchKernelGGL((k_trace_nq<true, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);

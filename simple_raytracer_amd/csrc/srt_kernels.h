@@ -337,7 +337,10 @@ __device__ __forceinline__ void diag_tile_record(float* rgb_linear, uint32_t bx,
 
 // The phase runs per wavefront on LDS the caller provides: nq[NQCAP], tq[QCAP], best[P], dir[P].  On return the
 // lanes < P hold their pixel's hit id and t (also written to hit_id / t_out, with the final pixel for misses).
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER>
+// CAM: camera mode (srt_params.ray_matrix): the rays start at the camera's position in the scene's space and their directions have
+// three varying components, so the phase keeps (dx, dy, dz) per ray, takes the reciprocals per test and tests triangles in the general
+// form (P1, e1, e2 and the ray's origin) instead of the origin form -- the arithmetic of the oracle's camera mode.
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool CAM = false>
 __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq,
                                                   unsigned long long* best, float4* dir,
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
@@ -355,12 +358,13 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     const uint32_t tile_x = (bx * 2 + (wave & 1)) << TWL, tile_r = (by * 2 + (wave >> 1)) << THL;
     const uint32_t px = tile_x + (lane & ((1u << TWL) - 1)), r = tile_r + ((lane >> TWL) & ((1u << THL) - 1));
     const bool live = lane < P && pixel_live(p, px, r);
-    const V3 o = mk(0.0f, 0.0f, 0.0f);
+    const V3 o = CAM ? ray_origin(p) : mk(0.0f, 0.0f, 0.0f);
     V3 dmine = mk(0.f, 0.f, p.focal);
     if (lane < P) {
         best[lane] = ~0ull;
         if (live) dmine = primary_dir(p, px, image_row(p, r));
-        dir[lane] = make_float4(dmine.x, dmine.y, __builtin_amdgcn_rcpf(dmine.x), __builtin_amdgcn_rcpf(dmine.y));   // + reciprocals for the filtered slab test
+        if (CAM) dir[lane] = make_float4(dmine.x, dmine.y, dmine.z, 0.f);
+        else dir[lane] = make_float4(dmine.x, dmine.y, __builtin_amdgcn_rcpf(dmine.x), __builtin_amdgcn_rcpf(dmine.y));   // + reciprocals for the filtered slab test
     }
     const float rcp_focal = __builtin_amdgcn_rcpf(p.focal);
     const unsigned long long livem = __ballot(live);
@@ -391,20 +395,21 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             const uint32_t info = tq[2 * (tqn + pi)], pl = tq[2 * (tqn + pi) + 1];
             const uint32_t first = info >> LEAF_SHIFT, cnt = info & LEAF_MAX;
             const float4 dxy = dir[pl];
-            const V3 d = mk(dxy.x, dxy.y, p.focal);
+            const V3 d = mk(dxy.x, dxy.y, CAM ? dxy.z : p.focal);
             float bt = __builtin_inff();
             uint32_t bi = 0;
             // one triangle per iteration, the next one's three dwordx4 loads issued before the current test: a wave spends
             // most of its life behind s_waitcnt, and the all-lanes-rejected exits of a single test skip more code than two
             // interleaved tests could (measured: 5 % of the launch); ids rise inside a lane, so strict '<' keeps the first minimum
-            const float4* tp = reinterpret_cast<const float4*>(s.tris_o) + ((size_t)first + sub) * 3;
+            const float4* tp = reinterpret_cast<const float4*>(CAM ? (const void*)s.tris : (const void*)s.tris_o) + ((size_t)first + sub) * 3;
             float4 n0, n1, n2;
             if (sub < cnt) { n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
             for (uint32_t k = sub; k < cnt; k += S) {
                 const float4 a0 = n0, a1 = n1, a2 = n2;
                 if (k + S < cnt) { tp += 3 * S; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }      // the next triangle's record is in flight during this test
                 if (COUNT) n_tri++;
-                const float ta = ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
+                const float ta = CAM ? ray_triangle(o, d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x))
+                                     : ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
                 // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
                 if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
             }
@@ -490,13 +495,15 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
 #ifdef SRT_DIAG
                 { unsigned long long c_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SRT_STAMP(c_); dg_load += c_ - dg_a; dg_a = c_; }
 #endif
-                d = mk(dxy.x, dxy.y, p.focal);
+                d = mk(dxy.x, dxy.y, CAM ? dxy.z : p.focal);
                 skip = __float_as_int(b.z); info = __float_as_int(b.w);
                 if (COUNT) n_node++;
                 bool pass;
                 if (FILTER) {
                     bool amb;
-                    RayRcp rc; rc.x = dxy.z; rc.y = dxy.w; rc.z = rcp_focal;
+                    RayRcp rc;
+                    if (CAM) rc = ray_rcp(d);
+                    else { rc.x = dxy.z; rc.y = dxy.w; rc.z = rcp_focal; }
                     pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
                     if (amb) pass = ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y);      // rare: exact divides decide
                 } else {
@@ -617,7 +624,7 @@ __device__ __forceinline__ bool background_test_wave(const DevScene& s, const De
     const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
     const uint32_t px = bx * 8 + (quad & 1) * 4 + (ql & 3), r = by * 8 + (quad >> 1) * 4 + (ql >> 2);
     const bool live = pixel_live(p, px, r);
-    const V3 o = mk(0.f, 0.f, 0.f);
+    const V3 o = ray_origin(p);                                        // (0 unless camera mode)
     const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
     const RayRcp rc = ray_rcp(dd);
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
@@ -1168,7 +1175,7 @@ __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevPara
 // in LDS (its shadow masks are there already) and bumps an LDS counter, and the wave that finds the other three done shades the
 // tile's 64 pixels, one per lane -- what k_shade_tile does in a second launch from hit ids, t and shadow words re-read from
 // memory.  Up to 63 light samples (one group of masks); `shadow_bits` may be null then (nobody reads the words).
-template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false>
+template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false>
 __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                               float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                               unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
@@ -1207,9 +1214,9 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
     unsigned long long ka = 0, kb = 0; (void)ka; (void)kb;
     SRT_STAMP(ka);
-    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
-                                                  roots_done ? root_pass + wave * 16 : nullptr);
+    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER, CAM>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+                                                       hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
+                                                       roots_done ? root_pass + wave * 16 : nullptr);
     __builtin_amdgcn_wave_barrier();
     SRT_STAMP(kb);
     shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
@@ -1235,11 +1242,11 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     }
 }
 
-template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false>
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false, bool CAM = false>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
-    trace_nq_body<COUNT, NQCAP, FILTER, RS, XCD_ROWS, ROOTS_AGAIN>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, counters);
+    trace_nq_body<COUNT, NQCAP, FILTER, RS, XCD_ROWS, ROOTS_AGAIN, false, CAM>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, counters);
 }
 // closest hit, shadow rays and shading of a frame in one launch (SHADE)
 template <int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false>
