@@ -616,7 +616,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
 // One WAVE puts the 64 rays of tile (bx, by) through every object's root box; if none passes any it writes the tile's background
 // pixels (and all-clear shadow words).  Returns (wave-uniform) whether the tile is live; root_pass (LDS, 64 words, quadrant * 16 +
 // pixel) receives, per ray, the objects whose root box it passes.
-template <bool FILTER>
+template <bool FILTER, bool CAM = false>
 __device__ __forceinline__ bool background_test_wave(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                      float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                      unsigned long long* __restrict__ shadow_bits,
@@ -624,7 +624,7 @@ __device__ __forceinline__ bool background_test_wave(const DevScene& s, const De
     const uint32_t lane = threadIdx.x & 63, quad = lane >> 4, ql = lane & 15u;
     const uint32_t px = bx * 8 + (quad & 1) * 4 + (ql & 3), r = by * 8 + (quad >> 1) * 4 + (ql >> 2);
     const bool live = pixel_live(p, px, r);
-    const V3 o = ray_origin(p);                                        // (0 unless camera mode)
+    const V3 o = CAM ? ray_origin(p) : mk(0.f, 0.f, 0.f);
     const V3 dd = live ? primary_dir(p, px, image_row(p, r)) : mk(0.f, 0.f, p.focal);
     const RayRcp rc = ray_rcp(dd);
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
@@ -660,7 +660,7 @@ __device__ __forceinline__ bool background_test_wave(const DevScene& s, const De
     return m != 0ull;
 }
 
-template <bool FILTER>
+template <bool FILTER, bool CAM = false>
 __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                        float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                        unsigned long long* __restrict__ shadow_bits,
@@ -668,7 +668,7 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
                                                        uint32_t* root_pass = nullptr) {      // LDS, 64 words (quadrant * 16 + pixel): out, per ray the objects whose root box it passes
     __shared__ uint32_t tile_live;
     if ((threadIdx.x >> 6) == 0) {
-        const bool live = background_test_wave<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass);
+        const bool live = background_test_wave<FILTER, CAM>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass);
         if ((threadIdx.x & 63) == 0) tile_live = live ? 1u : 0u;
     }
     __syncthreads();
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     }
     __shared__ uint32_t root_pass[64];
     const bool roots_done = !COUNT && !ROOTS_AGAIN && s.n_objects <= 32u;              // wave 0 tests every root for the tile's 64 rays first
-    if (!COUNT && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
+    if (!COUNT && finish_background_tile<FILTER, CAM>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
     unsigned long long ka = 0, kb = 0; (void)ka; (void)kb;
     SRT_STAMP(ka);
     closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER, CAM>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
