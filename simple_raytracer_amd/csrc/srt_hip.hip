@@ -548,7 +548,7 @@ static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) 
 
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
-    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22)) return SRT_ERR_ARG;      // camera mode: shipped pipeline only
+    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22 && ((p->flags >> 8) & 0xffu) != 35)) return SRT_ERR_ARG;      // camera mode: shipped pipelines only
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     if (p->block_cols && ((p->block_cols & 7u) || (p->block_rows & 7u) || p->block_first >= p->block_stride)) return SRT_ERR_ARG;   // tiles of whole 8x8 pixel blocks
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;

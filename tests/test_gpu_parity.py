@@ -257,6 +257,25 @@ def test_camera_mode_matches_oracle(srt, oracle, L):
         assert np.array_equal(o2["hit_id"], o["hit_id"]) and np.array_equal(bits(o2["rgb_linear"]), bits(o["rgb_linear"]))
     with pytest.raises(srt.SrtError):
         ds.render(abi.make_params(W, H, lights, ray_matrix=view, flags=10 << 8))        # only the shipped pipeline takes a camera matrix
+    if L < 8:
+        # a scene of a few MB with 1..7 samples takes the fused node-queue kernel's camera build; variant 35 = the packet closest-hit
+        # kernel as for the big scene above: both against the oracle, and bit for bit against each other
+        bunny_world = scenes.ground_bunny(T)                    # (any scene is a world-space scene for a camera)
+        fb = host.build_flat_scene(bunny_world, {k: gu.load_mesh(k) for k in bunny_world.meshes})
+        db = srt.DeviceScene(fb)
+        lb = abi.light_staircase(bunny_world.light, 3)
+        for angle in (-90.0, -82.0, -101.0):              # yaw = angle + 90 degrees: the camera stays near the origin and looks down +z
+            view = scenes.orbit_view_matrix(T, 12.0, angle, -5.0, 3.0)
+            a = db.render(abi.make_params(192, 108, lb, ray_matrix=view))
+            assert db.pipeline == "k_trace_nq+k_shade_tile"
+            b = db.render(abi.make_params(192, 108, lb, ray_matrix=view, flags=35 << 8))
+            assert db.pipeline.startswith("k_closest_hit_pk")
+            c = oracle.render(fb, abi.make_params(192, 108, lb, ray_matrix=view))
+            assert (c["hit_id"] >= 0).sum() > 1000
+            for o in (a, b):
+                assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"])), angle
+                assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR * max(1.0, float(np.abs(c["rgb_linear"]).max()))
+            assert np.array_equal(bits(a["rgb_linear"]), bits(b["rgb_linear"])) and np.array_equal(a["rgb8"], b["rgb8"])
 
 
 def test_scene_update_reuses_the_device_scene(srt, oracle):
