@@ -33,6 +33,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (32 lanes per cycle), so the chip's peak is
+# 1024 SIMDs x 32 lane-operations per cycle (x 2 flop x 2.4 GHz = the guide's 157.3 TFLOP/s FP32 vector peak); measured on the GPU
+# by tests/test_gpu_parity.py::test_valu_issue_rate_is_the_guides (independent v_fma_f32 streams, 8 waves per SIMD)
+N_SIMD, SIMD_LANES, VALU_CYCLES_PER_WAVE_INST = 1024.0, 32.0, 2.0
 NODE_BYTES, TRI_BYTES = 32, 36  # algorithmic bytes per slab test / Moller-Trumbore test
 BLOCK_ROWS = 8                  # scanline block size for the multi-GPU block-cyclic split
 BLOCK_COLS = 0                  # > 0: tiles of 8 x BLOCK_COLS pixels dealt in two dimensions (srt_params.block_cols); measured: no gain over whole-width blocks
@@ -77,6 +81,10 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / valu come from profiles/traffic.json, labelled)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block")
     ap.add_argument("--variant", type=int, default=0, help="experimental kernel selector (srt_params.flags bits 8-15)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the N-rank plumbing WITHOUT a GPU (CPU tests): self-launch, rendezvous (gloo), block-cyclic ownership, the "
+                         "gather, rank 0's assembly and the per-phase times -- the tiles carry a rank pattern instead of rendered pixels; no "
+                         "throughput is reported (`value` null)")
     ap.add_argument("--no-soup", action="store_true",
                     help="skip the second, short measurement the default workload adds: the 1 M-triangle soup at the same resolution and split "
                          "(north_star asks for the 1 / 2 / 4 / 8-GPU curve on the soup; it is reported as `soup` beside the headline value)")
@@ -111,8 +119,14 @@ def setup(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    # only one process compiles (ranks share the source tree); the others wait for it
-    if rank == 0:
+    # only one process compiles (ranks share the source tree); the others wait for it.  Under rocprofv3 nothing is compiled: the
+    # profiler's preloaded library has initialised the GPU, and starting hipcc / g++ / make from here would be the exec hop this pool
+    # forbids -- the artefacts must be fresh already (profiles/pmc_run.sh and tools/collect_profiles.sh build first)
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        stale = build.stale_artefacts()
+        if stale:
+            raise SystemExit(f"bench.py under the profiler will not compile: stale or missing {stale}; run `python -m simple_raytracer_amd.build` first")
+    elif rank == 0:
         build.build_all()
     if world > 1:
         dist.barrier()
@@ -287,6 +301,15 @@ def measure(args):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # what the TIMED region wrote (replayed hipGraph, frames overlapped on S streams or batched): frame 0's buffers -- handle 0 renders
+    # frames 0, S, 2S, ... of a step, all the same picture -- copied out before anything else renders into them
+    timed = None
+    last_slot = (args.warmup + args.steps - 1) % SLOTS if (args.warmup + args.steps) else 0
+    if rank == 0 and world == 1 and not emu and not args.no_parity:
+        timed = (hit[0].cpu().numpy().copy(), tbuf[0].cpu().numpy().copy(), lin[0].cpu().numpy().copy(), gather.tiles[last_slot][0].cpu().numpy().copy())
+    # the phases of a step one by one (N > 1: the SCALE records need them to be read)
+    phases = phase_times(gather, (lambda slot: graphs[slot].replay()) if graphs is not None else (lambda slot: render_frames(p, slot)),
+                         world, dev, args.backend) if world > 1 else None
     # N > 1: what rank 0 holds after the last gather must be the frame one GPU renders (every step renders the same frames)
     gathered_ok = None
     if world > 1 and rank == 0 and FG == 1 and gather.frame is not None:
@@ -302,10 +325,11 @@ def measure(args):
     st = scene.sync()
     rgb8 = gather.tiles[0][0]
 
-    # buffers of the last eager (shipped-pipeline) frame, for the parity block: the counting launch below reuses them
-    keep = None
-    if rank == 0 and world == 1 and not emu and not args.no_parity:
-        keep = (hit[0].cpu().numpy().copy(), tbuf[0].cpu().numpy().copy(), lin[0].cpu().numpy().copy(), rgb8.cpu().numpy().copy())
+    # the eager single-stream re-render of the same frame must be bitwise what the timed region (graph replay) wrote
+    eager_equal = None
+    if timed is not None:
+        eager = (hit[0].cpu().numpy(), tbuf[0].cpu().numpy(), lin[0].cpu().numpy(), rgb8.cpu().numpy())
+        eager_equal = bool(all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(timed, eager)))
     # ---- ray and work accounting (one extra untimed launch of the counting build) -----------------
     pc = abi.make_params(W, H, lights, block_rows=p.block_rows, block_first=p.block_first, block_stride=p.block_stride, block_cols=p.block_cols,
                          flags=abi.SRT_FLAG_COUNT_WORK | (args.variant << 8), spp=args.spp)
@@ -317,7 +341,10 @@ def measure(args):
     # ---- parity of the frame the timed region rendered last (rank 0, whole frames only) -------------------------------
     parity = None
     if rank == 0 and world == 1 and not emu and not args.no_parity:
-        parity = parity_block(g, args, W, H, L, lights, *keep)
+        parity = parity_block(g, args, W, H, L, lights, *timed)
+        parity["frame_compared"] = ("frame 0 of the last step of the TIMED region (" + ("hipGraph replay" if graph is not None else "eager launches") +
+                                    f", {S} stream(s)), copied out before any other render")
+        parity["eager_rerender_bitwise_equal"] = eager_equal
     if world > 1:
         rr = torch.tensor([rays_rank / FG, sc["primary_rays"] / FG, sc["shadow_rays"] / FG], dtype=torch.float64,        # summed over ranks: one whole frame
                           device=dev if args.backend == "nccl" else "cpu")
@@ -371,10 +398,10 @@ def measure(args):
             insts_f = sum(v["SQ_INSTS_VALU"] for v in pk.values())
             lanes_f = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in pk.values()) / insts_f if insts_f else 0.0
             cyc_f = (ms_step / B_total) * 1e-3 * roof["valu"]["clock_GHz"] * 1e9
-            issue_f = insts_f * 4.0 / (1024.0 * cyc_f) if cyc_f else 0.0
-            roof["timed_region"] = {"valu_issue_frac": round(min(issue_f, 1.0), 4), "lanes_active_of_64": round(lanes_f, 1),
-                                    "frac_of_lane_peak": round(min(issue_f, 1.0) * lanes_f / 64.0, 4), "kernels": sorted(pk),
-                                    "note": "VALU wave-instructions of ALL kernels of a frame (counters of the kernels running alone) x 4 / (1024 SIMDs x the cycles a frame "
+            issue_f = insts_f * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * cyc_f) if cyc_f else 0.0
+            roof["timed_region"] = {"valu_issue_frac": round(issue_f, 4), "lanes_active_of_64": round(lanes_f, 1),
+                                    "frac_of_lane_peak": round(issue_f * lanes_f / 64.0, 4), "kernels": sorted(pk),
+                                    "note": "VALU wave-instructions of ALL kernels of a frame (counters of the kernels running alone) x 2 / (1024 SIMDs x the cycles a frame "
                                             "takes in the timed region): what the overlap of frames on streams adds to the single kernel's `frac`"}
         roof["kernel_ms_note"] = ("HIP events around eager launches on ONE stream (the kernel running alone, as in profiles/*_kernel_stats.csv and the --pmc "
                                   f"passes); the timed region overlaps the frames of a step on {S} stream(s), where a per-kernel duration is not defined")
@@ -384,6 +411,7 @@ def measure(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
             **({"gathered_frames_equal_one_gpu_render": gathered_ok} if gathered_ok is not None else {}),
+            **(phases if phases is not None else {}),
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
                        else (f"{args.workload} {W}x{H} {L} light(s) [BASELINE.json configs[1]]" if args.workload == "cube_ground"
@@ -392,8 +420,9 @@ def measure(args):
                              else f"k4: composite scene (ground cube, bunny, 3 textured trees, horse, house without its 'Plane'; 223,855 triangles, 8 textures), "
                                   f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[3]]" if args.workload == "k4"
                              else f"soup: {args.tris} random triangles, {W}x{H}, {L} light sample(s), spp {args.spp} [BASELINE.json configs[4]]"),
-                       "scene": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
-                                f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
+                       "scene": "static, resident; no per-frame update (the frames of a step are renders of ONE scene already in HBM: a hot-path rate, not an orbit's frame rate)",
+                       "scene_source": f"tests/golden/scene_{args.workload}.npz" if args.workload != "soup" else
+                                       f"SplitMix64(0x5eed) soup, {args.tris} triangles in 4 objects, built by the host mirror (SURVEY.md s8d K5)",
                        "nodes": g.flat.n_nodes, "tris": g.flat.n_tris,
                        "parallelism": "1 GPU" if world == 1 else
                                       (f"the {B_total} frames of a step dealt to {FG} group(s) of {per_group} GPU(s); inside a group " +
@@ -416,9 +445,119 @@ def measure(args):
     return None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell (no torchrun around it, WORLD_SIZE unset): this process -- which has not touched
+    HIP or torch.cuda -- starts N fresh child processes of the same command line, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1), lets rank 0's JSON line through on stdout and returns the worst exit
+    code.  A rank that dies takes the others with it (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.05)
+        for pr in list(alive):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            alive.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                for other in alive:                              # exact children of this process
+                    other.terminate()
+    return worst
+
+
+def dry_run(args):
+    """--dry-run: the N-rank plumbing of measure() without a GPU -- process group (gloo), ownership tables, one equal-size gather per
+    step into rank 0 (double-buffered as in the measured path), assembly, the per-phase clocks and the JSON line's N > 1 fields.
+    The tiles carry a pattern (image row, image column, frame) that rank 0 checks after assembly.  Nothing is rendered and no
+    throughput is claimed."""
+    import torch
+    import torch.distributed as dist
+    from simple_raytracer_amd import tiling
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+    W, H, B = args.width, args.height, args.frames
+    dev = torch.device("cpu")
+    BC = args.block_cols if world > 1 else 0
+    fg = tiling.FrameGather(W, H, args.block_rows if world > 1 else H, rank, world, dev, frames=B, slots=2 if world > 1 else 1, block_cols=BC)
+    pm = torch.as_tensor(fg.pix_of[rank])                          # image pixel of every local pixel (-1 = padding)
+    def fill(slot, step):
+        y, x = (pm // W).clamp(min=0), (pm % W).clamp(min=0)
+        for f in range(B):
+            t = fg.tiles[slot][f, : fg.rows, : fg.cols]
+            t[..., 0] = (y % 251).to(torch.uint8); t[..., 1] = (x % 241).to(torch.uint8); t[..., 2] = (f * 7 + step) % 256
+    t_render = t_gather = t_asm = 0.0
+    for step in range(args.warmup + args.steps):
+        slot = step % len(fg.tiles)
+        fg.finish(slot)
+        t0 = time.perf_counter(); fill(slot, step); t_render += time.perf_counter() - t0
+        fg.start(slot)
+    frame = fg.finish_all()
+    ph = phase_times(fg, lambda slot: fill(slot, 99), world, dev, "gloo", reps=2)
+    ok = None
+    if rank == 0:
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        got = fg.frame if world > 1 else fg.tiles[0][:, :H, :W]      # (one rank: its tile IS the frame)
+        ok = bool(torch.equal(got[0, ..., 0], (yy % 251).to(torch.uint8)) and torch.equal(got[0, ..., 1], (xx % 241).to(torch.uint8))
+                  and int(got[B - 1, 0, 0, 2]) == ((B - 1) * 7 + 99) % 256)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "Mrays/sec (primary+shadow) at 1920x1080; max per-pixel |dRGB| vs CPU ref", "value": None, "unit": "Mrays/s",
+                          "dry_run": "no GPU: N-rank plumbing only (self-launch, gloo rendezvous, ownership, gather, assembly); tiles carry a pattern",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "assembled_frames_ok": ok, **ph}), flush=True)
+    return 0 if (ok or rank != 0) else 1
+
+
+def phase_times(gather, render_slot, world, dev, backend, reps=3):
+    """What a step is made of, phase by phase and NOT overlapped (the timed region overlaps them: the gather of step s runs beside the
+    rendering of step s + 1, and rank 0 assembles on a stream of its own): render (max over ranks), the collective, rank 0's assembly.
+    Measured after the timed region with a barrier before every phase.  `gather_bytes` is what rank 0 receives per step."""
+    import torch
+    import torch.distributed as dist
+    cuda = torch.device(dev).type == "cuda"
+    def sync():
+        if cuda:
+            torch.cuda.synchronize()
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(reps):
+        barrier(); t0 = time.perf_counter(); render_slot(0); sync(); acc[0] += time.perf_counter() - t0
+        if world > 1:
+            barrier(); t0 = time.perf_counter(); gather.start(0); gather.wait_collective(0); sync(); acc[1] += time.perf_counter() - t0
+            barrier(); t0 = time.perf_counter(); gather.finish(0); gather.wait_assembly(); sync(); acc[2] += time.perf_counter() - t0
+    vals = [a / reps * 1e3 for a in acc]
+    if world > 1:
+        tt = torch.tensor(vals, dtype=torch.float64, device=dev if (cuda and backend == "nccl") else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        vals = [float(x) for x in tt.tolist()]
+    tile_bytes = gather.tiles[0].numel() * gather.tiles[0].element_size()
+    return {"render_ms_max": round(vals[0], 4), "gather_ms": round(vals[1], 4) if world > 1 else 0.0, "assemble_ms": round(vals[2], 4) if world > 1 else 0.0,
+            "gather_bytes": int(tile_bytes * (world - 1)) if world > 1 else 0,
+            "phase_note": "per step, each phase alone behind a barrier (max over ranks); the timed region overlaps the gather and rank 0's assembly with the next step's rendering"}
+
+
 def main():
     import copy
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
     out = measure(args)
     rank, _, world = setup(args)
     if args.workload == "ground_bunny" and not args.no_soup and not args.emulate_split and args.spp == 1 and args.variant == 0:
@@ -451,7 +590,11 @@ class soup_workload:
         self.recipe = None          # no reference replay for this workload in cpu_reference()
 
 
-PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"],
+              # what the kernel waits for (roofline.limiter): wave-cycle split, then the vector-memory path
+              ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INST_LEVEL_VMEM"],
+              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TA_BUSY_avr"]]
+PMC_REQUIRED = 3        # the first three groups carry the roofline; a failed limiter pass only drops `limiter`
 
 
 def collect_pmc(argv, kernel):
@@ -487,6 +630,9 @@ def collect_pmc(argv, kernel):
             r = subprocess.run([exe, "--kernel-trace", "--pmc", *grp, "--output-format", "csv", "-d", d, "--"] + child,
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             if r.returncode:
+                if i >= PMC_REQUIRED:
+                    print(f"bench: rocprofv3 pass {grp} failed (rc {r.returncode}); roofline.limiter will lack these counters", file=sys.stderr)
+                    continue
                 print(f"bench: rocprofv3 pass {grp} failed (rc {r.returncode}); using profiles/traffic.json", file=sys.stderr)
                 return None
             acc, acc_all = {}, {}
@@ -539,9 +685,11 @@ def committed_pmc(workload, kernel, W, H, L):
 def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
     """The bound is chosen from counters, not assumed.  HBM: (2 x FETCH_SIZE + WRITE_SIZE) per launch (KiB; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for 16-B-per-lane reads on gfx950 -- an upper bound for the narrower ones) over the launch time
-    against 8 TB/s.  VALU: a wave64 VALU instruction holds its SIMD for 4 cycles, so wave-instructions x 4 / (1024 SIMDs x launch
-    cycles) is the issue utilisation; times the active lanes per instruction / 64 it is the fraction of the lane-operation peak
-    (1024 SIMDs x 16 lanes x clock).  bound = "hbm" when the HBM fraction is at least 25 % and the larger of the two, else "valu".
+    against 8 TB/s.  VALU: CDNA4 has SIMD-32 -- a wave64 VALU instruction issues over 2 cycles -- so wave-instructions x 2 / (1024
+    SIMDs x launch cycles) is the issue utilisation; times the active lanes per instruction / 64 it is the fraction of the
+    lane-operation peak (1024 SIMDs x 32 lanes x clock = the guide's 157.3 TFLOP/s FP32 vector peak / 2 flop).  bound = "hbm" when the
+    HBM fraction is at least 25 % and the larger of the two, else "valu".  `limiter` names what the dominant kernel actually waits for,
+    from the vector-memory counters of the same passes (a kernel far below both peaks is bound by latency, not by a throughput).
     The algorithmic-bytes rate of SURVEY.md s8(d) is kept as a labelled EFFECTIVE figure: records come from L2 / Infinity Cache."""
     scene_mb = (g.flat.n_nodes * 32 + g.flat.n_tris * 96) / 1e6
     eff = {"effective_algorithmic_GBps": round(effective_gbs, 2), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
@@ -556,11 +704,7 @@ def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
     clock_ghz = cycles / (prof_ms * 1e6)
     insts = c["SQ_INSTS_VALU"]
     lanes = (c.get("SQ_THREAD_CYCLES_VALU", 0.0) / insts) if insts else 0.0
-    issue = insts * 4.0 / (1024.0 * cycles) if cycles else 0.0
-    issue_note = None
-    if issue > 1.0:      # measured on the packet closest-hit kernel: 1.11.  Some VALU instructions of a wave64 issue in fewer than 4 cycles, so
-        issue_note = f"wave-instructions x 4 / SIMD-cycles = {issue:.3f} > 1: the 4-cycles-per-instruction yardstick is exceeded, i.e. the VALUs are saturated; capped at 1"
-        issue = 1.0
+    issue = insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * cycles) if cycles else 0.0
     valu_frac = issue * lanes / 64.0
     traffic = pmc.get("traffic_bytes")
     if traffic is None:
@@ -570,13 +714,46 @@ def roofline_block(kernel, kernel_ms, algorithmic_bytes, effective_gbs, pmc, g):
     common = {"kernel": kernel, "kernel_ms": round(kernel_ms, 5), "kernel_ms_under_profiler": round(prof_ms, 5), "traffic": int(traffic),
               "hbm_GBps": round(hbm_gbs, 1), "hbm_frac": round(hbm_frac, 4),
               "valu": {"wave_insts_per_launch": int(insts), "launch_cycles": int(cycles), "clock_GHz": round(clock_ghz, 3), "issue_frac": round(issue, 4),
-                       "lanes_active_of_64": round(lanes, 1), "frac_of_lane_peak": round(valu_frac, 4), **({"note": issue_note} if issue_note else {})},
-              "source": pmc["source"], **eff}
+                       "lanes_active_of_64": round(lanes, 1), "frac_of_lane_peak": round(valu_frac, 4),
+                       "yardstick": "SIMD-32: wave-instructions x 2 cycles / (1024 SIMDs x launch cycles) x active lanes / 64"},
+              "limiter": limiter_block(c, cycles), "source": pmc["source"], **eff}
     if hbm_frac >= 0.25 and hbm_frac >= valu_frac:
         return {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), **common}
-    peak = 1024 * 16 * clock_ghz / 1e3                          # T lane-operations / s at the clock the launch ran at
+    peak = N_SIMD * SIMD_LANES * clock_ghz / 1e3                # T lane-operations / s at the clock the launch ran at
     return {"bound": "valu", "achieved": round(insts * lanes / (prof_ms * 1e-3) / 1e12, 3), "peak": round(peak, 3), "unit": "Tlaneop/s",
             "frac": round(valu_frac, 4), **common}
+
+
+def limiter_block(c, cycles):
+    """What the dominant kernel waits for, from the SQ / TA / TCP counters of the same child passes (per launch means).  SQ_WAVE_CYCLES,
+    SQ_WAIT_ANY, SQ_ACTIVE_INST_* count quad-cycles summed over waves; TA / TCP counters are summed over the 256 CUs' instances."""
+    if not c.get("SQ_WAVE_CYCLES"):
+        return None
+    wc = c["SQ_WAVE_CYCLES"]
+    out = {"wave_cycles_waiting_frac": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+           "wave_cycles_issue_stalled_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+           "wave_cycles_valu_frac": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
+           "wave_cycles_vmem_frac": round(c.get("SQ_ACTIVE_INST_VMEM", 0.0) / wc, 4),
+           "wave_cycles_lds_frac": round(c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4)}
+    cu_cycles = 256.0 * cycles
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") is not None and cu_cycles:
+        out["l1_tag_lookups_per_cu_cycle"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / cu_cycles, 4)
+    if c.get("TA_BUSY_avr") is not None and cycles:
+        out["ta_busy_frac"] = round(c["TA_BUSY_avr"] / cycles, 4)
+    if c.get("TCP_PENDING_STALL_CYCLES_sum") is not None and cu_cycles:
+        out["l1_pending_on_l2_stall_frac"] = round(c["TCP_PENDING_STALL_CYCLES_sum"] / cu_cycles, 4)
+    if c.get("TCP_TCP_TA_DATA_STALL_CYCLES_sum") is not None and cu_cycles:
+        out["l1_data_return_stall_frac"] = round(c["TCP_TCP_TA_DATA_STALL_CYCLES_sum"] / cu_cycles, 4)
+    if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_INST_LEVEL_VMEM"):
+        out["vmem_latency_cycles"] = round(c["SQ_INST_LEVEL_VMEM"] / c["SQ_INSTS_VMEM_RD"], 1)
+    w = out["wave_cycles_waiting_frac"]
+    if w >= 0.5:
+        out["name"] = "latency: waves parked behind s_waitcnt (vector-memory gathers of node / triangle records through the L1) most of their life"
+    elif out["wave_cycles_valu_frac"] >= 0.5:
+        out["name"] = "VALU issue"
+    else:
+        out["name"] = "mixed: issue and memory waits"
+    return out
 
 
 def parity_block(g, args, W, H, L, lights, hit, t, lin, rgb8):
@@ -629,8 +806,11 @@ def cpu_reference(g, W, H):
     """The reference's OWN hot path (oracle/_ref, compiled from its sources in the build container), one
     thread as the reference is, one frame of the same workload.  Extra context beside cpu_baseline."""
     from oracle import pyoracle as po
-    if not po.ref_available() or g.recipe is None:
+    if g.recipe is None:
         return None
+    if not po.ref_available():          # said loudly: the compiled reference is git-ignored and has to travel with the snapshot
+        print("bench: oracle/_ref/libsrt_ref.so did not travel to this box: no cpu_reference leg", file=sys.stderr)
+        return {"absent": "oracle/_ref/libsrt_ref.so is not on this box (built from /root/reference by oracle/Makefile in the build container; git-ignored, shipped by gpurun)"}
     import golden_util as gu
     try:
         s = po.RefScene()

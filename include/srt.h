@@ -178,8 +178,9 @@ int srt_scene_share(srt_scene* src, srt_scene** out);
 
 /* The next frame's geometry into the SAME device allocations (the reference re-transforms and rebuilds everything per frame,
  * simple_raytracer.cpp:534-618): `desc` must have the counts of the scene's current contents (n_objects, n_nodes, n_tris,
- * n_textures, the same triangles textured / with normals), else SRT_ERR_LAYOUT -- create a new scene then.  Texture images are
- * NOT re-uploaded (they rarely change between frames; tri_tex / tri_texcoord are).  Asynchronous on `stream`: the copies are
+ * n_textures, the same triangles textured / with normals) and the texture table of the uploaded scene (tex_off, tex_w, tex_h), else
+ * SRT_ERR_LAYOUT -- create a new scene then.  Texture images are uploaded again only when their bytes differ from what the device
+ * holds (a 64-bit content hash is compared; they rarely change between frames); tri_tex / tri_texcoord always are.  Asynchronous on `stream`: the copies are
  * ordered behind the renders already enqueued there (NULL = the scene's own stream, the one srt_render / srt_render_async use);
  * the descriptor's arrays are only read during the call. */
 int srt_scene_update(srt_scene* s, const srt_scene_desc* desc, void* stream);
@@ -252,6 +253,11 @@ int srt_kat_phong(int device, uint32_t n, const float* in28, float* rgb);
 int srt_kat_interp_normal(int device, uint32_t n, const float* in12 /* 3 normals + barycentrics */, float* out3);   /* interpolateNormal :132-140 */
 int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* fast, float* lib);   /* the device powf: shipped form vs (float)pow(double) */
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q);
+
+/* Measurement hook: the chip's VALU issue rate from independent v_fma_f32 streams at 8 waves per SIMD (the yardstick bench.py's
+ * roofline prices the kernels' VALU work against).  out[0] = wave-instructions one SIMD issues per cycle (MI355X: SIMD-32, a wave64
+ * instruction over 2 cycles -> 0.5), out[1] = shader clock in GHz during the run, out[2] = the same rate over the whole launch span. */
+int srt_debug_valu_rate(int device, uint32_t iters, double* out3);
 
 /* Test hook: the next n host allocations made on behalf of a caller fail (std::bad_alloc inside the library), so that
  * the SRT_ERR_OOM path can be exercised without exhausting memory.  Not for production use. */

@@ -109,6 +109,19 @@ def build_c_example(force=False, verbose=False):
     return EXAMPLE_C
 
 
+def stale_artefacts():
+    """Names of the product's native artefacts that are missing or older than their sources (nothing is built)."""
+    hdir = os.path.join(CSRC, "host")
+    hip_deps = [os.path.join(CSRC, f) for f in ("srt_hip.hip", "srt_device.h", "srt_kernels.h", "srt_packet.h")] + [os.path.join(HERE, "..", "include", "srt.h")]
+    host_deps = [os.path.join(hdir, f) for f in ("srt_host.cpp", "srt_jpeg.cpp", "srt_host_c.cpp", "srt_host.h")]
+    out = []
+    if _stale(LIB_HIP, hip_deps):
+        out.append("libsrt_hip.so")
+    if _stale(LIB_HOST, host_deps):
+        out.append("libsrt_host.so")
+    return out
+
+
 def build_all(force=False, verbose=False):
     return [build_hip(force, verbose), build_host(force, verbose), build_examples(force, verbose), build_c_example(force, verbose)]
 

@@ -44,6 +44,22 @@ struct __attribute__((aligned(16))) DevTriO {
 };
 static_assert(sizeof(DevTriO) == 48, "origin-ray triangle record is 48 B");
 
+// Inner node as the node-queue kernels read it: 64 B = four dwordx4 -- BOTH children's boxes and what each child is.  A queue
+// entry then names an inner node that is already KNOWN to pass (its box was tested from its parent's record), one pop loads one
+// record and runs the two slab tests of boundingBoxIntersection:305-313 side by side (independent: the second hides the first's
+// latencies), and only passing children are queued.  Same boxes, same predicate, every (node, ray) pair still tested exactly once,
+// when its parent passes -- but half the pops, LDS pushes and dependent record loads per ray of the 32 B form.
+// Records are numbered in pre-order over the INNER nodes only (leaves have none); `linfo` / `rinfo`: a leaf child's
+// (first_triangle << 5 | count) >= 0, or ~(record index of an inner child) < 0; `node` / `rnode`: the pre-order node indices of this
+// node and of its right child (the left child is node + 1), for the stackless walk that takes over when the queue is full.
+struct __attribute__((aligned(16))) DevWide {
+    float lminx, lminy, lminz, lmaxx;
+    float lmaxy, lmaxz, rminx, rminy;
+    float rminz, rmaxx, rmaxy, rmaxz;
+    int32_t linfo, rinfo, node, rnode;
+};
+static_assert(sizeof(DevWide) == 64, "wide inner-node record is 64 B");
+
 constexpr int LEAF_SHIFT = 5;
 constexpr int NODE_INDEX_BITS = 26;      // a node-queue entry is (node index << 6 | ray lane) in 32 bits
 constexpr int LEAF_MAX = (1 << LEAF_SHIFT) - 1;
@@ -130,6 +146,40 @@ __device__ __forceinline__ bool ray_aabb_filtered(V3 o, RayRcp rc, float mnx, fl
     const float df = tfar - tnear;
     ambiguous = !(__builtin_fabsf(df) > m);            // also true when df is NaN or m is inf
     return df > 0.0f;
+}
+
+// The predicate as the kernels call it: the filter where it can decide, the reference's comparisons with exact divides where not.
+template <bool FILTER>
+__device__ __forceinline__ bool slab_pass(V3 o, V3 d, RayRcp rc, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+    if (FILTER) {
+        bool amb;
+        bool pass = ray_aabb_filtered(o, rc, mnx, mny, mnz, mxx, mxy, mxz, amb);
+        if (amb) pass = ray_aabb_nb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
+        return pass;
+    }
+    return ray_aabb_nb(o, d, mnx, mny, mnz, mxx, mxy, mxz);
+}
+// Both children of a DevWide record (r0..r2 = its first three dwordx4) for one ray.  The two filtered tests are independent
+// instruction streams; the exact form behind them is ONE block of code that runs once per ambiguous box (rare).
+template <bool FILTER>
+__device__ __forceinline__ void slab_pass2(V3 o, V3 d, RayRcp rc, float4 r0, float4 r1, float4 r2, bool& passL, bool& passR) {
+    if (FILTER) {
+        bool ambL, ambR;
+        passL = ray_aabb_filtered(o, rc, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, ambL);
+        passR = ray_aabb_filtered(o, rc, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, ambR);
+        if (ambL | ambR) {
+#pragma nounroll
+            for (int c = 0; c < 2; c++) {
+                if (c ? ambR : ambL) {
+                    const bool e = ray_aabb_nb(o, d, c ? r1.z : r0.x, c ? r1.w : r0.y, c ? r2.x : r0.z, c ? r2.y : r0.w, c ? r2.z : r1.x, c ? r2.w : r1.y);
+                    if (c) passR = e; else passL = e;
+                }
+            }
+        }
+    } else {
+        passL = ray_aabb_nb(o, d, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+        passR = ray_aabb_nb(o, d, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w);
+    }
 }
 
 // ---- a5: rayTriangleIntersection, simple_raytracer.cpp:42-75 (Moller-Trumbore) ------------------

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -57,6 +58,8 @@ constexpr int RING = 64;         // HIP-event triples kept for per-kernel timing
 struct SceneRecords {
     int device = 0;
     std::vector<void*> allocs;
+    std::vector<uint64_t> tex_off; std::vector<uint32_t> tex_w, tex_h;      // the uploaded texture table (host copy) ...
+    uint64_t tex_bytes = 0, tex_hash = 0;                                    // ... and the size and content hash of the uploaded images
     double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
     bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
     ~SceneRecords() { (void)hipSetDevice(device); for (void* d : allocs) (void)hipFree(d); }
@@ -75,7 +78,7 @@ struct srt_scene {
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
-    struct FrameTable { std::vector<FrameItem> host; FrameItem* dev = nullptr; size_t n = 0; uint64_t stamp = 0; };
+    struct FrameTable { std::vector<FrameItem> host; FrameItem* dev = nullptr; size_t n = 0; uint64_t stamp = 0; bool pinned = false; };      // pinned: handed out to a capturing stream (a graph may replay it for ever)
     std::vector<FrameTable> tables;               // argument tables of the batches this handle led (srt_render_device_batch)
     uint64_t table_clock = 0;
     char pipeline[96] = "";                       // kernels of the last render, in launch order
@@ -305,6 +308,49 @@ static int build_device_records(const srt_scene_desc* d, DevNode* nodes, int2* r
     return SRT_OK;
 }
 
+// The inner nodes as the node-queue kernels read them (DevWide, srt_device.h): both children's boxes in the parent's record, records
+// numbered in pre-order over the inner nodes.  wide[n_wide], root_info[n_objects]; n_wide = (n_nodes - n_objects) / 2 for full binary
+// trees, which build_device_records has checked.  widx is scratch (n_nodes words).
+static uint32_t wide_count(uint32_t n_nodes, uint32_t n_objects) { return (n_nodes - n_objects) / 2; }
+static void build_wide_records(const DevNode* nodes, uint32_t n_nodes, const int2* ranges, uint32_t n_objects, DevWide* wide, int32_t* root_info, int32_t* widx) {
+    int32_t w = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) widx[i] = nodes[i].leaf < 0 ? w++ : -1;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i].leaf >= 0) continue;
+        const DevNode& l = nodes[i + 1];
+        const int32_t ri = ~nodes[i].leaf;
+        const DevNode& r = nodes[ri];
+        DevWide& q = wide[widx[i]];
+        q.lminx = l.minx; q.lminy = l.miny; q.lminz = l.minz; q.lmaxx = l.maxx; q.lmaxy = l.maxy; q.lmaxz = l.maxz;
+        q.rminx = r.minx; q.rminy = r.miny; q.rminz = r.minz; q.rmaxx = r.maxx; q.rmaxy = r.maxy; q.rmaxz = r.maxz;
+        q.linfo = l.leaf >= 0 ? l.leaf : ~widx[i + 1];
+        q.rinfo = r.leaf >= 0 ? r.leaf : ~widx[ri];
+        q.node = (int32_t)i; q.rnode = ri;
+    }
+    for (uint32_t k = 0; k < n_objects; k++) {
+        const int32_t root = ranges[k].x;
+        root_info[k] = nodes[root].leaf >= 0 ? nodes[root].leaf : ~widx[root];
+    }
+}
+
+// 64-bit content hash of a byte range (texture images: srt_scene_update re-uploads them only when it changes).  Eight independent
+// multiply-xor lanes over 64-byte blocks: memory-bound on one core.
+static uint64_t content_hash(const uint8_t* p, size_t n) {
+    uint64_t h[8];
+    for (int k = 0; k < 8; k++) h[k] = 0x9e3779b97f4a7c15ull * (uint64_t)(k + 1) ^ (uint64_t)n;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        uint64_t w[8];
+        std::memcpy(w, p + i, 64);
+        for (int k = 0; k < 8; k++) { h[k] = (h[k] ^ w[k]) * 0xff51afd7ed558ccdull; h[k] ^= h[k] >> 29; }
+    }
+    uint64_t tail[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (i < n) { std::memcpy(tail, p + i, n - i); for (int k = 0; k < 8; k++) { h[k] = (h[k] ^ tail[k]) * 0xff51afd7ed558ccdull; h[k] ^= h[k] >> 29; } }
+    uint64_t r = 0xc4ceb9fe1a85ec53ull;
+    for (int k = 0; k < 8; k++) { r = (r ^ h[k]) * 0xff51afd7ed558ccdull; r ^= r >> 32; }
+    return r;
+}
+
 // How many slab tests does a ray cost?  Surface-area estimate: a random line that crosses the scene's bounds crosses a convex
 // box inside them with probability area(box) / area(bounds), and a node is tested when its parent's box is crossed.  A good
 // hierarchy gives a few dozen (bunny: boxes shrink with depth); a median split by first vertex of a random soup gives hundreds
@@ -344,10 +390,17 @@ static void derive_triangles(const srt_scene_desc* d, DevTri* tris, DevTriO* tri
     unsigned hc = std::thread::hardware_concurrency();
     const uint32_t T = n < 32768 ? 1u : (hc >= 8 ? 8u : (hc >= 2 ? hc : 1u));
     if (T == 1) { derive_range(0, n); return; }
+    // a thread that cannot be started (std::system_error) must not take the process down with joinable threads in a dying vector:
+    // the ranges that got no thread are derived inline, and every started thread is joined
     std::vector<std::thread> th;
+    th.reserve(T);
     const uint32_t step = (n + T - 1) / T;
-    for (uint32_t k = 1; k < T; k++) th.emplace_back(derive_range, k * step < n ? k * step : n, (k + 1) * step < n ? (k + 1) * step : n);
+    uint32_t started = 1;                                  // ranges [1, started) have a thread
+    try {
+        for (; started < T; started++) th.emplace_back(derive_range, started * step < n ? started * step : n, (started + 1) * step < n ? (started + 1) * step : n);
+    } catch (...) { }
     derive_range(0, step < n ? step : n);
+    for (uint32_t k = started; k < T; k++) derive_range(k * step < n ? k * step : n, (k + 1) * step < n ? (k + 1) * step : n);
     for (std::thread& t : th) t.join();
 }
 
@@ -397,6 +450,9 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     rc = build_device_records(d, nodes.data(), ranges.data());
     if (rc != SRT_OK) return rc;
     const double overlap = overlap_estimate(nodes.data(), d->n_nodes, ranges.data(), d->n_objects);
+    const uint32_t n_wide = wide_count(d->n_nodes, d->n_objects);
+    std::vector<DevWide> wide(n_wide); std::vector<int32_t> root_info(d->n_objects);
+    { std::vector<int32_t> widx(d->n_nodes); build_wide_records(nodes.data(), d->n_nodes, ranges.data(), d->n_objects, wide.data(), root_info.data(), widx.data()); }
     std::vector<DevTri> tris(d->n_tris);
     std::vector<DevTriO> tris_o(d->n_tris);
     derive_triangles(d, tris.data(), tris_o.data());
@@ -411,6 +467,8 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     s->rec = std::make_shared<SceneRecords>(); s->rec->device = device;
     #define UP(expr) do { rc = (expr); if (rc != SRT_OK) { srt_scene_destroy(s); return rc; } } while (0)
     UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
+    UP(upload(s, wide.data(), wide.size(), &s->dev.wide));
+    UP(upload(s, root_info.data(), root_info.size(), &s->dev.obj_root_info));
     UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
     UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
     UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
@@ -440,6 +498,9 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
         UP(upload(s, size.data(), size.size(), &s->dev.tex_size));
         UP(upload(s, d->tex_w, d->n_textures, &s->dev.tex_w));
         UP(upload(s, d->tex_h, d->n_textures, &s->dev.tex_h));
+        s->rec->tex_off.assign(d->tex_off, d->tex_off + d->n_textures);
+        s->rec->tex_w.assign(d->tex_w, d->tex_w + d->n_textures); s->rec->tex_h.assign(d->tex_h, d->tex_h + d->n_textures);
+        s->rec->tex_bytes = total; s->rec->tex_hash = content_hash(d->tex_rgb, (size_t)total);
     }
     #undef UP
     s->dev.n_nodes = d->n_nodes; s->dev.n_tris = d->n_tris; s->dev.n_objects = d->n_objects;
@@ -490,13 +551,32 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     if (d->n_textures && d->tri_tex) for (uint32_t i = 0; i < d->n_tris; i++) any_tex |= d->tri_tex[i] >= 0;
     if (d->n_objects != s->dev.n_objects || d->n_nodes != s->dev.n_nodes || d->n_tris != s->dev.n_tris || d->n_textures != s->n_textures ||
         any_tex != s->has_tex || (d->tri_normals != nullptr) != (s->dev.tri_normals != nullptr)) return SRT_ERR_LAYOUT;      // counts differ: create a new scene
+    // Texture images: the table (offsets, sizes) must be the uploaded one -- the kernels index with the uploaded tex_w / tex_off --
+    // and the image bytes are uploaded again when their content hash differs from what is on the device.  (A second scene with the
+    // same counts but other pictures, handed to a renderer that keeps one device scene, must not be shaded with the first one's.)
+    size_t tex_total = 0;
+    bool tex_changed = false;
+    uint64_t tex_hash_new = 0;
+    if (any_tex) {
+        SceneRecords& r = *s->rec;
+        for (uint32_t k = 0; k < d->n_textures; k++) {
+            if (d->tex_off[k] != r.tex_off[k] || d->tex_w[k] != r.tex_w[k] || d->tex_h[k] != r.tex_h[k]) return SRT_ERR_LAYOUT;      // another table: create a new scene
+            const size_t end = (size_t)d->tex_off[k] + (size_t)d->tex_w[k] * d->tex_h[k] * 3;
+            if (end > tex_total) tex_total = end;
+        }
+        if (tex_total != r.tex_bytes) return SRT_ERR_LAYOUT;
+        tex_hash_new = content_hash(d->tex_rgb, tex_total);
+        tex_changed = tex_hash_new != r.tex_hash;
+    }
     HIP_TRY(hipSetDevice(s->device));
-    const size_t nN = d->n_nodes, nT = d->n_tris, nO = d->n_objects;
+    const size_t nN = d->n_nodes, nT = d->n_tris, nO = d->n_objects, nW = wide_count(d->n_nodes, d->n_objects);
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_nodes = 0, o_tris = o_nodes + pad(nN * sizeof(DevNode)), o_triso = o_tris + pad(nT * sizeof(DevTri)),
                  o_triobj = o_triso + pad(nT * sizeof(DevTriO)), o_ranges = o_triobj + pad(nT * 4), o_first = o_ranges + pad(nO * sizeof(int2)),
                  o_color = o_first + pad((nO + 1) * 4), o_mat = o_color + pad(nO * 12), o_nrm = o_mat + pad(nO * 12),
-                 o_tex = o_nrm + pad(d->tri_normals ? nT * 36 : 0), o_tc = o_tex + pad(any_tex ? nT * 4 : 0), total = o_tc + pad(any_tex ? nT * 24 : 0);
+                 o_tex = o_nrm + pad(d->tri_normals ? nT * 36 : 0), o_tc = o_tex + pad(any_tex ? nT * 4 : 0), o_wide = o_tc + pad(any_tex ? nT * 24 : 0),
+                 o_rinfo = o_wide + pad(nW * sizeof(DevWide)), o_widx = o_rinfo + pad(nO * 4), o_img = o_widx + pad(nN * 4),
+                 total = o_img + pad(tex_changed ? tex_total : 0);
     if (s->stage_bytes < total) {
         if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
         HIP_TRY(hipHostMalloc(&s->stage, total, hipHostMallocDefault));
@@ -509,6 +589,8 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     DevNode* nodes = (DevNode*)(h + o_nodes); int2* ranges = (int2*)(h + o_ranges);
     rc = build_device_records(d, nodes, ranges);
     if (rc != SRT_OK) return rc;
+    build_wide_records(nodes, d->n_nodes, ranges, d->n_objects, (DevWide*)(h + o_wide), (int32_t*)(h + o_rinfo), (int32_t*)(h + o_widx));
+    if (tex_changed) std::memcpy(h + o_img, d->tex_rgb, tex_total);
     derive_triangles(d, (DevTri*)(h + o_tris), (DevTriO*)(h + o_triso));
     derive_tri_first(d, (int32_t*)(h + o_first));
     std::memcpy(h + o_triobj, d->tri_obj, nT * 4);
@@ -518,6 +600,9 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     if (any_tex) { std::memcpy(h + o_tex, d->tri_tex, nT * 4); std::memcpy(h + o_tc, d->tri_texcoord, nT * 24); }
     #define CP(dst, off, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync((void*)(dst), h + (off), (bytes), hipMemcpyHostToDevice, stream)); } while (0)
     CP(s->dev.nodes, o_nodes, nN * sizeof(DevNode));
+    CP(s->dev.wide, o_wide, nW * sizeof(DevWide));
+    CP(s->dev.obj_root_info, o_rinfo, nO * 4);
+    if (tex_changed) { CP(s->dev.tex, o_img, tex_total); s->rec->tex_hash = tex_hash_new; }
     CP(s->dev.tris, o_tris, nT * sizeof(DevTri));
     CP(s->dev.tris_o, o_triso, nT * sizeof(DevTriO));
     CP(s->dev.tri_obj, o_triobj, nT * 4);
@@ -548,7 +633,7 @@ static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) 
 
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
-    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22 && ((p->flags >> 8) & 0xffu) != 35)) return SRT_ERR_ARG;      // camera mode: shipped pipelines only
+    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22 && ((p->flags >> 8) & 0xffu) != 35 && ((p->flags >> 8) & 0xffu) != 41)) return SRT_ERR_ARG;      // camera mode: shipped pipelines only
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     if (p->block_cols && ((p->block_cols & 7u) || (p->block_rows & 7u) || p->block_first >= p->block_stride)) return SRT_ERR_ARG;   // tiles of whole 8x8 pixel blocks
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
@@ -647,7 +732,12 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
     const bool coarse_grid = variant == 27;                // 27: variant 0 with 2 x 2 tiles per workgroup in the unfused closest-hit launch (A/B, not shipped)
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    const bool narrow = variant == 40 || variant == 42;    // 40: variant 0 with the node-queue kernels on the 32 B node records (a queue entry = a node still to be tested: the round-2 form, A/B)
+    dp.exp = (variant == 41 || variant == 42 || variant == 43) ? 1u : 0u;   // 41 / 42: variants 0 / 40 with the node queues kept in node-major order (A/B); 43: 41 built for 5 waves per SIMD
+    dp.pad2_ = 0u;
+    const bool wide5 = variant == 43;
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || narrow || variant == 41) variant = 0;
+    if (wide5) variant = 11;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -759,6 +849,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 12) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // round-1 form: roots re-tested per wave (A/B)
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
+                else if (narrow)        hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, false, false, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else if (bc && !count && (p->flags >> 8 & 0xffu) == 0 && pk_shadow && !pk_closest && spp == 1 && bc->accepts(wl, rows)) {
@@ -775,6 +866,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // dispatch-bound, and a workgroup that walks its live tiles one after the other is a longer tail
                 hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, true>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream,
                                    s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
+            } else if (narrow && !count) {
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }
@@ -799,6 +892,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (narrow)       hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);      // 80 VGPRs: six waves per SIMD (86 without the bound: five)
             HIP_TRY(hipGetLastError());
         }
@@ -869,18 +963,21 @@ constexpr size_t FRAME_TABLES_KEPT = 128;      // (a table is 352 bytes a frame)
 static int frame_table(srt_scene* owner, const std::vector<FrameItem>& items, hipStream_t stream, const FrameItem** out) {
     const size_t bytes = items.size() * sizeof(FrameItem);
     *out = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(stream, &cap));
     for (auto& e : owner->tables) {
-        if (e.n != items.size() || std::memcmp(e.host.data(), items.data(), bytes) != 0) continue;
+        if (e.n != items.size() || std::memcmp(e.host.data(), items.data(), bytes) != 0) continue;      // (the records have no implicit padding: static_asserts in srt_kernels.h)
         e.stamp = ++owner->table_clock;
+        if (cap != hipStreamCaptureStatusNone) e.pinned = true;      // a captured graph keeps reading this table: never evicted
         *out = e.dev;
         return SRT_OK;
     }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    HIP_TRY(hipStreamIsCapturing(stream, &cap));
     if (cap != hipStreamCaptureStatusNone) return SRT_OK;
-    if (owner->tables.size() >= FRAME_TABLES_KEPT) {            // forget the table used longest ago (hipFree waits for the device)
-        size_t old = 0;
-        for (size_t k = 1; k < owner->tables.size(); k++) if (owner->tables[k].stamp < owner->tables[old].stamp) old = k;
+    if (owner->tables.size() >= FRAME_TABLES_KEPT) {            // forget the table used longest ago that no graph can hold (hipFree waits for the device)
+        size_t old = owner->tables.size();
+        for (size_t k = 0; k < owner->tables.size(); k++)
+            if (!owner->tables[k].pinned && (old == owner->tables.size() || owner->tables[k].stamp < owner->tables[old].stamp)) old = k;
+        if (old == owner->tables.size()) return SRT_ERR_LIMIT;  // every remembered batch belongs to a captured graph
         (void)hipFree(owner->tables[old].dev);
         owner->tables.erase(owner->tables.begin() + old);
     }
@@ -1148,6 +1245,44 @@ int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* f
     HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     KAT_TRY(o.down(fast, (size_t)n * 4));
     return o2.down(lib, (size_t)n * 4);
+}
+
+// out[0] = VALU wave-instructions one SIMD issues per cycle (median over waves of 64 * iters / cycles, x the 8 waves that share a
+// SIMD), out[1] = shader clock in GHz during the run (s_memtime against the 100 MHz s_memrealtime), out[2] = the same rate from the
+// chip-wide span (all waves' instructions / (1024 SIMDs x clock x (last end - first start))), which includes launch ramp and tail.
+int srt_debug_valu_rate(int device, uint32_t iters, double* out) {
+    if (!iters || !out) return SRT_ERR_ARG;
+    return guarded([&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const uint32_t n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    const uint32_t wgs = n_cu * 8u;                            // 8 workgroups of 4 waves per CU = 8 waves per SIMD, all resident
+    DevBuf sink, st;
+    KAT_TRY(sink.alloc((size_t)wgs * 256 * 4)); KAT_TRY(st.alloc((size_t)wgs * 4 * 4 * 8));
+    for (int rep = 0; rep < 2; rep++) {                        // the first launch warms the clock
+        hipLaunchKernelGGL(k_valu_rate, dim3(wgs), dim3(256), 0, 0, iters, (float*)sink.p, (unsigned long long*)st.p);
+        HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> h((size_t)wgs * 16);
+    KAT_TRY(st.down(h.data(), h.size() * 8));
+    const size_t nw = (size_t)wgs * 4;
+    std::vector<double> per_wave(nw), clk(nw);
+    unsigned long long rmin = ~0ull, rmax = 0;
+    for (size_t w = 0; w < nw; w++) {
+        const unsigned long long t0 = h[4 * w], t1 = h[4 * w + 1], r0 = h[4 * w + 2], r1 = h[4 * w + 3];
+        per_wave[w] = 64.0 * iters / (double)(t1 - t0);
+        clk[w] = (double)(t1 - t0) / (double)(r1 - r0) * 0.1;      // GHz: ticks per 10 ns
+        if (r0 < rmin) rmin = r0;
+        if (r1 > rmax) rmax = r1;
+    }
+    std::nth_element(per_wave.begin(), per_wave.begin() + nw / 2, per_wave.end());
+    std::nth_element(clk.begin(), clk.begin() + nw / 2, clk.end());
+    out[0] = per_wave[nw / 2] * 8.0;
+    out[1] = clk[nw / 2];
+    out[2] = (64.0 * iters * (double)nw) / ((double)n_cu * 4.0 * out[1] * 1e9 * ((double)(rmax - rmin) * 1e-8));
+    return SRT_OK;
+    });
 }
 
 int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, float gamma, float* tone, int32_t* q) {

@@ -12,6 +12,8 @@ using namespace srt;
 // =================================================================================================
 struct DevScene {
     const DevNode* nodes;
+    const DevWide* wide;          // inner nodes with both children's boxes (node-queue kernels), pre-order over inner nodes
+    const int32_t* obj_root_info; // n_objects: what an object's ROOT is -- ~(its DevWide index) < 0, or a leaf's (first << 5 | count)
     const DevTri* tris;
     const DevTriO* tris_o;        // the same triangles as rays from the origin test them (closest-hit phase)
     const int32_t* tri_obj;
@@ -28,7 +30,9 @@ struct DevScene {
     const uint32_t* tex_h;
     const unsigned long long* tex_size;
     uint32_t n_nodes, n_tris, n_objects;
+    uint32_t pad_;                // explicit: argument tables are compared bytewise (frame_table), so no implicit padding anywhere
 };
+static_assert(sizeof(DevScene) == 18 * 8 + 16, "DevScene has no implicit padding");
 
 struct DevParams {
     uint32_t W, H, rows;          // W = width of the rows this call writes (local width); rows of them
@@ -47,7 +51,9 @@ struct DevParams {
     uint32_t shadow_px_major;     // shadow bits as the packet shadow kernel writes them: per pixel one u64 per 64 light samples
     uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
     float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
+    uint32_t exp, pad2_;          // experiment switches (A/B variants, wave-uniform branches): bit 0 = node-major queue order
 };
+static_assert(sizeof(DevParams) == 152, "DevParams has no implicit padding");
 
 // counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
 __device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
@@ -314,7 +320,7 @@ __device__ __forceinline__ void quadrant_list_append(uint32_t* __restrict__ qcou
 }
 
 constexpr int NQ_P = 16;                    // rays per wavefront of the shadow kernel (4x4 pixel quadrant)
-constexpr int LQ_WORDS = 2 * (64 + 64);     // (leaf, ray) pair queue of the node-queue kernels: < 64 left over + <= 64 per push, 2 words each
+constexpr int LQ_WORDS = 2 * (64 + 128);    // (leaf, ray) pair queue of the node-queue kernels: < 64 left over + <= 128 per push (two children per lane), 2 words each
 
 // TWL / THL: log2 of the tile width / height a wavefront owns (shipped: 4x4); FILTER: filtered slab predicate.
 #ifdef SRT_DIAG
@@ -340,7 +346,9 @@ __device__ __forceinline__ void diag_tile_record(float* rgb_linear, uint32_t bx,
 // CAM: camera mode (srt_params.ray_matrix): the rays start at the camera's position in the scene's space and their directions have
 // three varying components, so the phase keeps (dx, dy, dz) per ray, takes the reciprocals per test and tests triangles in the general
 // form (P1, e1, e2 and the ray's origin) instead of the origin form -- the arithmetic of the oracle's camera mode.
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool CAM = false>
+// WIDE: the queue holds inner nodes that are known to pass, as indices of their DevWide records (srt_device.h): a pop tests BOTH
+// children.  !WIDE is the round-1/2 form (a queue entry is a node still to be tested, 32 B records), kept for A/B (variant 40).
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool CAM = false, bool WIDE = false>
 __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq,
                                                   unsigned long long* best, float4* dir,
                                                   int32_t* __restrict__ hit_id, float* __restrict__ t_out,
@@ -437,9 +445,146 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         }
     };
 
+    // the same for up to two passing leaves per lane (the two children of a DevWide record)
+    auto push_tris2 = [&](uint32_t info_a, bool leaf_a, uint32_t info_b, bool leaf_b, uint32_t pl) {
+        const unsigned long long ma = __ballot(leaf_a), mb = __ballot(leaf_b);
+        if (ma | mb) {
+            uint32_t pos = tqn + lane_prefix(ma) + lane_prefix(mb), q = pos + (leaf_a ? 1u : 0u);
+            if (p.exp & 1u) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
+            if (leaf_a) { tq[2 * pos] = info_a; tq[2 * pos + 1] = pl; }
+            if (leaf_b) { tq[2 * q] = info_b; tq[2 * q + 1] = pl; }
+            tqn += (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
+            __builtin_amdgcn_wave_barrier();
+            while (tqn >= 64) tri_batch();
+        }
+    };
+
     const uint32_t n_obj = s.n_objects;
     const uint32_t nlive = (uint32_t)__popcll(livem);
     constexpr uint32_t OBJ_G = (NQCAP / (2 * P)) < 16 ? (NQCAP / (2 * P)) : 16;      // roots pushed at once: P * OBJ_G <= NQCAP / 2
+    if constexpr (WIDE) {
+    const float4* wide4 = reinterpret_cast<const float4*>(s.wide);
+    for (uint32_t obj0 = 0; obj0 < n_obj && nlive; obj0 += OBJ_G) {
+        const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
+        // the roots: either tested already (root_pass: wave 0 ran them for the whole tile with full lanes) or tested here, one (ray,
+        // object) pair per lane; a passing root that is an inner node is queued, a passing leaf's triangles are
+        for (uint32_t base = 0; base < P * g; base += 64) {
+            const uint32_t k = base + lane;
+            const uint32_t pl = k & (P - 1), ob = k >> (TWL + THL);
+            bool ok = k < P * g && ((livem >> pl) & 1ull);
+            if (!COUNT && root_pass) ok = ok && ((root_pass[pl] >> (obj0 + ob)) & 1u);
+            else if (ok) {
+                const int32_t root = s.obj_range[obj0 + ob].x;
+                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+                const float4 dxy = dir[pl];
+                const V3 d = mk(dxy.x, dxy.y, CAM ? dxy.z : p.focal);
+                RayRcp rc;
+                if (CAM) rc = ray_rcp(d);
+                else { rc.x = dxy.z; rc.y = dxy.w; rc.z = rcp_focal; }
+                if (COUNT) n_node++;
+                ok = slab_pass<FILTER>(o, d, rc, a.x, a.y, a.z, a.w, b.x, b.y);
+            }
+            int32_t info = 0;
+            if (ok) info = s.obj_root_info[obj0 + ob];
+            const bool inner = ok && info < 0, leafp = ok && info >= 0 && (info & LEAF_MAX) != 0;
+            const unsigned long long im = __ballot(inner);
+            if (inner) nq[nqn + lane_prefix(im)] = ((uint32_t)(~info) << 6) | pl;
+            nqn += (uint32_t)__popcll(im);
+            push_tris2((uint32_t)info, leafp, 0u, false, pl);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (nqn) {
+            const uint32_t m = nqn < 64 ? nqn : 64;
+            nqn -= m;
+#ifdef SRT_DIAG
+            SRT_STAMP(dg_a); dg_steps++; dg_items += m;
+            const unsigned long long tri_before = dg_tri;
+#endif
+            const bool have = lane < m;
+            uint32_t pl = 0;
+            int32_t linfo = 0, rinfo = 0, node = 0, rnode = 0;
+            bool in_l = false, in_r = false, lf_l = false, lf_r = false;
+            V3 d = mk(0.f, 0.f, p.focal);
+            if (have) {
+                const uint32_t e = nq[nqn + lane];
+                pl = e & 63u;
+#ifdef SRT_DIAG
+                { unsigned long long c_; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SRT_STAMP(c_); dg_pop += c_ - dg_a; dg_a = c_; }
+#endif
+                const float4* wp = wide4 + 4 * (size_t)(e >> 6);
+                const float4 r0 = wp[0], r1 = wp[1], r2 = wp[2];
+                const int4 r3 = reinterpret_cast<const int4*>(wp)[3];
+                const float4 dxy = dir[pl];
+#ifdef SRT_DIAG
+                { unsigned long long c_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); SRT_STAMP(c_); dg_load += c_ - dg_a; dg_a = c_; }
+#endif
+                d = mk(dxy.x, dxy.y, CAM ? dxy.z : p.focal);
+                RayRcp rc;
+                if (CAM) rc = ray_rcp(d);
+                else { rc.x = dxy.z; rc.y = dxy.w; rc.z = rcp_focal; }
+                linfo = r3.x; rinfo = r3.y; node = r3.z; rnode = r3.w;
+                if (COUNT) n_node += 2;
+                bool pass_l, pass_r;
+                slab_pass2<FILTER>(o, d, rc, r0, r1, r2, pass_l, pass_r);
+                in_l = pass_l && linfo < 0; lf_l = pass_l && linfo >= 0 && (linfo & LEAF_MAX) != 0;
+                in_r = pass_r && rinfo < 0; lf_r = pass_r && rinfo >= 0 && (rinfo & LEAF_MAX) != 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+            SRT_STAMP(dg_b); dg_test += dg_b - dg_a;
+#endif
+            const unsigned long long ml = __ballot(in_l), mr = __ballot(in_r);
+            const uint32_t n_in = (uint32_t)__popcll(ml) + (uint32_t)__popcll(mr);
+            if (nqn + n_in <= (uint32_t)NQCAP) {
+                if (p.exp & 1u) {      // node-major: all right children, then all left children -- rays that visit one node stay neighbours
+                    if (in_r) nq[nqn + lane_prefix(mr)] = ((uint32_t)(~rinfo) << 6) | pl;
+                    if (in_l) nq[nqn + (uint32_t)__popcll(mr) + lane_prefix(ml)] = ((uint32_t)(~linfo) << 6) | pl;
+                } else {
+                const uint32_t pos = nqn + lane_prefix(ml) + lane_prefix(mr);
+                if (in_r) nq[pos] = ((uint32_t)(~rinfo) << 6) | pl;
+                if (in_l) nq[pos + (in_r ? 1u : 0u)] = ((uint32_t)(~linfo) << 6) | pl;      // left child on top: popped first
+                }
+                nqn += n_in;
+                push_tris2((uint32_t)linfo, lf_l, (uint32_t)rinfo, lf_r, pl);
+            } else {
+                // queue full: finish the passing children's subtrees with the stackless pre-order walk over the 32 B records
+                // (i = pass ? i + 1 : skip[i]).  Left subtree = nodes (node + 2 .. rnode), right = (rnode + 1 .. skip[rnode]); with both
+                // the walk runs through and hops over the right child itself, which has been tested above.
+                push_tris2((uint32_t)linfo, lf_l, (uint32_t)rinfo, lf_r, pl);
+                int32_t i = 0, end = 0, hop = -1;
+                if (in_l | in_r) {
+                    i = in_l ? node + 2 : rnode + 1;
+                    end = in_r ? s.nodes[rnode].skip : rnode;
+                    hop = (in_l && in_r) ? rnode : -1;
+                }
+                while (__ballot(i < end)) {
+                    int32_t inf2 = -1;
+                    bool lp2 = false;
+                    if (i < end) {
+                        if (i == hop) i = hop + 1;
+                        else {
+                            const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+                            const int32_t sk = __float_as_int(b.z);
+                            inf2 = __float_as_int(b.w);
+                            if (COUNT) n_node++;
+                            if (ray_aabb_nb(o, d, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                lp2 = inf2 >= 0 && (inf2 & LEAF_MAX) != 0;
+                                i = i + 1;
+                            } else {
+                                i = sk;
+                            }
+                        }
+                    }
+                    push_tris2((uint32_t)inf2, lp2, 0u, false, pl);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef SRT_DIAG
+            { unsigned long long c2_; SRT_STAMP(c2_); dg_commit += (c2_ - dg_b) - (dg_tri - tri_before); }
+#endif
+        }
+    }
+    } else
     for (uint32_t obj0 = 0; obj0 < n_obj && nlive; obj0 += OBJ_G) {
         // roots of up to OBJ_G objects for every live pixel, in chunks of 64 (node, pixel) pairs
         const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
@@ -455,9 +600,10 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                 const bool inner = ok && info < 0, leafp = ok && info >= 0 && (info & LEAF_MAX) != 0;
                 const unsigned long long im = __ballot(inner);
                 if (inner) {
-                    const uint32_t pos = nqn + 2 * lane_prefix(im);
+                    uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
+                    if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + (uint32_t)__popcll(im); }      // node-major
                     nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
-                    nq[pos + 1] = ((uint32_t)(root + 1) << 6) | pl;   // left child on top: popped first
+                    nq[pos1] = ((uint32_t)(root + 1) << 6) | pl;      // left child on top: popped first
                 }
                 nqn += 2 * (uint32_t)__popcll(im);
                 push_tris((uint32_t)info, leafp, pl);
@@ -522,9 +668,10 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             const uint32_t n_in = (uint32_t)__popcll(im);
             if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
                 if (inner) {
-                    const uint32_t pos = nqn + 2 * lane_prefix(im);
+                    uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
+                    if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }      // node-major
                     nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
-                    nq[pos + 1] = ((uint32_t)(node + 1) << 6) | pl;   // left child on top: popped first
+                    nq[pos1] = ((uint32_t)(node + 1) << 6) | pl;      // left child on top: popped first
                 }
                 nqn += 2 * n_in;
                 push_tris((uint32_t)info, leafp, pl);
@@ -679,7 +826,7 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
 // then work through the live tiles one after the other (four waves per tile, as ever).  For frames that are mostly background
 // (3840x2160 of the reference's scenes: 94 % of 129,600 tiles) the launch is bound by workgroup dispatch, and this is a quarter
 // of the workgroups; the host picks it for big frames only (a frame full of geometry keeps the finer grid's balance).
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false>
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false, bool WIDE = true>
 __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
                                                         uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
@@ -705,7 +852,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
         const bool roots_done = s.n_objects <= 32u;
         for (uint32_t k = 0; k < 4u; k++) {
             if (!live4[k]) continue;                                  // workgroup-uniform
-            closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+            closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER, false, WIDE>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                               hit_id, t_out, rgb_linear, rgb8, counters, id, t, d,
                                                               blockIdx.x * 2u + (k & 1u), blockIdx.y * 2u + (k >> 1), gx, wave, qcount, qlist, qcap,
                                                               roots_done ? root_pass4[k] + wave * 16 : nullptr);
@@ -715,7 +862,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p,
     __shared__ uint32_t root_pass[64];
     const bool roots_done = !COUNT && TWL == 2 && THL == 2 && s.n_objects <= 32u;      // wave 0 tests every root for the tile's 64 rays first
     if (!COUNT && TWL == 2 && THL == 2 && finish_background_tile<FILTER>(s, p, hit_id, t_out, rgb_linear, rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
-    closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+    closest_hit_phase<COUNT, NQCAP, TWL, THL, FILTER, false, WIDE>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                       hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave, qcount, qlist, qcap,
                                                       roots_done ? root_pass + wave * 16 : nullptr);
 }
@@ -854,7 +1001,7 @@ struct ShadowLds {
 // Runs per wavefront, with no workgroup-level synchronisation: `id` / `t_hit` are the hit id and t of this lane's pixel
 // (lanes < 16; -1 = miss).  The wave writes its own 16-bit field of the tile's word (field = quadrant, bit = pixel lane
 // y * 4 + x inside the quadrant), so a wave that is done leaves the CU without waiting for its three neighbours.
-template <bool SEQ, int NQCAP, bool FILTER, int RS, bool EARLY = true>
+template <bool SEQ, int NQCAP, bool FILTER, int RS, bool EARLY = true, bool WIDE = false>
 __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams& p, uint32_t* nq, uint32_t* tq, ShadowLds<RS>& L,
                                              int32_t id, float t_hit, V3 d_hit,
                                              unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
@@ -962,6 +1109,20 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         }
     };
 
+    auto push_tris2 = [&](uint32_t info_a, bool leaf_a, uint32_t info_b, bool leaf_b, uint32_t rs) {
+        const unsigned long long ma = __ballot(leaf_a), mb = __ballot(leaf_b);
+        if (ma | mb) {
+            uint32_t pos = tqn + lane_prefix(ma) + lane_prefix(mb), q = pos + (leaf_a ? 1u : 0u);
+            if (p.exp & 1u) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
+            if (leaf_a) { tq[2 * pos] = info_a; tq[2 * pos + 1] = rs; }
+            if (leaf_b) { tq[2 * q] = info_b; tq[2 * q + 1] = rs; }
+            tqn += (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
+            __builtin_amdgcn_wave_barrier();
+            while (tqn >= 64) tri_batch();
+        }
+    };
+    const float4* wide4 = reinterpret_cast<const float4*>(s.wide);
+
     constexpr uint32_t OBJ_G = (NQCAP / (2 * RS)) < 16 ? (NQCAP / (2 * RS)) : 16;     // RS * OBJ_G <= NQCAP / 2
     const uint32_t n_obj = s.n_objects;
     for (uint32_t l0 = l_begin; l0 < l_end; l0 += 64) {              // light samples in groups of 64
@@ -999,6 +1160,104 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                 }
                 const unsigned long long validm = __ballot(valid);
                 __builtin_amdgcn_wave_barrier();
+                if constexpr (WIDE) {
+                for (uint32_t obj0 = 0; obj0 < n_obj; obj0 += OBJ_G) {
+                    const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
+                    // the other objects' roots, one (ray, object) pair per lane: a passing inner root is queued, a passing leaf's triangles are
+                    for (uint32_t kb = 0; kb < RS * g; kb += 64) {
+                        const uint32_t k = kb + lane;
+                        const uint32_t rs = k & (RS - 1), ob = k / RS;
+                        bool ok = k < RS * g && ((validm >> rs) & 1ull);
+                        int32_t info = 0;
+                        if (ok) {
+                            const int32_t root = s.obj_range[obj0 + ob].x;
+                            ok = root != selfr[rs].x && !flag[rs];                 // never the hit object's own tree (:331)
+                            if (ok) {
+                                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+                                const float4 o4 = ray[rs], d4 = ray[RS + rs];
+                                const V3 ro = mk(o4.x, o4.y, o4.z), rd = mk(d4.x, d4.y, d4.z);
+                                ok = slab_pass<FILTER>(ro, rd, ray_rcp(rd), a.x, a.y, a.z, a.w, b.x, b.y);
+                                if (ok) info = s.obj_root_info[obj0 + ob];
+                            }
+                        }
+                        const bool inner = ok && info < 0, leafp = ok && info >= 0 && (info & LEAF_MAX) != 0;
+                        const unsigned long long im = __ballot(inner);
+                        if (inner) nq[nqn + lane_prefix(im)] = ((uint32_t)(~info) << 6) | rs;
+                        nqn += (uint32_t)__popcll(im);
+                        push_tris2((uint32_t)info, leafp, 0u, false, rs);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    while (nqn) {
+                        const uint32_t m = nqn < 64 ? nqn : 64;
+                        nqn -= m;
+                        uint32_t rs = 0;
+                        int32_t linfo = 0, rinfo = 0, node = 0, rnode = 0;
+                        bool in_l = false, in_r = false, lf_l = false, lf_r = false;
+                        V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
+                        if (lane < m) {
+                            const uint32_t e = nq[nqn + lane];
+                            rs = e & 63u;
+                            if (!flag[rs]) {                          // already shadowed rays drop their queued pairs
+                                const float4* wp = wide4 + 4 * (size_t)(e >> 6);
+                                const float4 r0 = wp[0], r1 = wp[1], r2 = wp[2];
+                                const int4 r3 = reinterpret_cast<const int4*>(wp)[3];
+                                const float4 o4 = ray[rs], d4 = ray[RS + rs];
+                                ro = mk(o4.x, o4.y, o4.z); rd = mk(d4.x, d4.y, d4.z);
+                                linfo = r3.x; rinfo = r3.y; node = r3.z; rnode = r3.w;
+                                bool pass_l, pass_r;
+                                slab_pass2<FILTER>(ro, rd, ray_rcp(rd), r0, r1, r2, pass_l, pass_r);
+                                in_l = pass_l && linfo < 0; lf_l = pass_l && linfo >= 0 && (linfo & LEAF_MAX) != 0;
+                                in_r = pass_r && rinfo < 0; lf_r = pass_r && rinfo >= 0 && (rinfo & LEAF_MAX) != 0;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long ml = __ballot(in_l), mr = __ballot(in_r);
+                        const uint32_t n_in = (uint32_t)__popcll(ml) + (uint32_t)__popcll(mr);
+                        if (nqn + n_in <= (uint32_t)NQCAP) {
+                            if (p.exp & 1u) {
+                                if (in_r) nq[nqn + lane_prefix(mr)] = ((uint32_t)(~rinfo) << 6) | rs;
+                                if (in_l) nq[nqn + (uint32_t)__popcll(mr) + lane_prefix(ml)] = ((uint32_t)(~linfo) << 6) | rs;
+                            } else {
+                            const uint32_t pos = nqn + lane_prefix(ml) + lane_prefix(mr);
+                            if (in_r) nq[pos] = ((uint32_t)(~rinfo) << 6) | rs;
+                            if (in_l) nq[pos + (in_r ? 1u : 0u)] = ((uint32_t)(~linfo) << 6) | rs;
+                            }
+                            nqn += n_in;
+                            push_tris2((uint32_t)linfo, lf_l, (uint32_t)rinfo, lf_r, rs);
+                        } else {
+                            // queue full: the passing children's subtrees by the stackless walk (see closest_hit_phase)
+                            push_tris2((uint32_t)linfo, lf_l, (uint32_t)rinfo, lf_r, rs);
+                            int32_t i = 0, end = 0, hop = -1;
+                            if (in_l | in_r) {
+                                i = in_l ? node + 2 : rnode + 1;
+                                end = in_r ? s.nodes[rnode].skip : rnode;
+                                hop = (in_l && in_r) ? rnode : -1;
+                            }
+                            while (__ballot(i < end)) {
+                                int32_t inf2 = -1;
+                                bool lp2 = false;
+                                if (i < end) {
+                                    if (flag[rs]) i = end;
+                                    else if (i == hop) i = hop + 1;
+                                    else {
+                                        const float4 a = nodes4[2 * (size_t)i], b = nodes4[2 * (size_t)i + 1];
+                                        const int32_t sk = __float_as_int(b.z);
+                                        inf2 = __float_as_int(b.w);
+                                        if (ray_aabb_nb(ro, rd, a.x, a.y, a.z, a.w, b.x, b.y)) {
+                                            lp2 = inf2 >= 0 && (inf2 & LEAF_MAX) != 0;
+                                            i = i + 1;
+                                        } else {
+                                            i = sk;
+                                        }
+                                    }
+                                }
+                                push_tris2((uint32_t)inf2, lp2, 0u, false, rs);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                } else
                 for (uint32_t obj0 = 0; obj0 < n_obj; obj0 += OBJ_G) {
                     const uint32_t g = (n_obj - obj0) < OBJ_G ? (n_obj - obj0) : OBJ_G;
                     for (uint32_t kb = 0; kb < RS * g; kb += 64) {
@@ -1046,9 +1305,10 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                         const uint32_t n_in = (uint32_t)__popcll(im);
                         if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
                             if (inner) {
-                                const uint32_t pos = nqn + 2 * lane_prefix(im);
+                                uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
+                                if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }
                                 nq[pos] = ((uint32_t)(~info) << 6) | rs;
-                                nq[pos + 1] = ((uint32_t)(node + 1) << 6) | rs;
+                                nq[pos1] = ((uint32_t)(node + 1) << 6) | rs;
                             }
                             nqn += 2 * n_in;
                             push_tris((uint32_t)info, leafp, rs);
@@ -1094,7 +1354,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
 
 // blockIdx.z = chunk of `l_chunk` light samples: with many samples a tile's shadow rays are cut over several workgroups (a
 // wave that walks 16 pixels x 64 samples through dense geometry alone can outlast the rest of the launch)
-template <bool SEQ, int NQCAP, bool FILTER, int RS = 16, int MINW = 1>
+template <bool SEQ, int NQCAP, bool FILTER, int RS = 16, int MINW = 1, bool WIDE = true>
 __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                    const float* __restrict__ t_in, unsigned long long* __restrict__ shadow_bits,
                                                    unsigned long long* __restrict__ counters, uint32_t l_chunk = 0xffffffffu) {
@@ -1107,7 +1367,7 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && pixel_live(p, px, r)) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
     const uint32_t l_begin = l_chunk == 0xffffffffu ? 0u : blockIdx.z * l_chunk;
-    shadow_phase<SEQ, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave,
+    shadow_phase<SEQ, NQCAP, FILTER, RS, true, WIDE>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave,
                                          l_begin, l_chunk == 0xffffffffu ? 0xffffffffu : l_begin + l_chunk);
 }
 
@@ -1175,7 +1435,7 @@ __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevPara
 // in LDS (its shadow masks are there already) and bumps an LDS counter, and the wave that finds the other three done shades the
 // tile's 64 pixels, one per lane -- what k_shade_tile does in a second launch from hit ids, t and shadow words re-read from
 // memory.  Up to 63 light samples (one group of masks); `shadow_bits` may be null then (nobody reads the words).
-template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false>
+template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false, bool WIDE = true>
 __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                               float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                               unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
@@ -1214,12 +1474,12 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     if (!COUNT && finish_background_tile<FILTER, CAM>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, bx, by, gx, root_pass)) return;
     unsigned long long ka = 0, kb = 0; (void)ka; (void)kb;
     SRT_STAMP(ka);
-    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER, CAM>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+    closest_hit_phase<COUNT, NQCAP, 2, 2, FILTER, CAM, WIDE>(s, p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                        hit_id, t_out, rgb_linear, rgb8, counters, id, t, d, bx, by, gx, wave, nullptr, nullptr, 0,
                                                        roots_done ? root_pass + wave * 16 : nullptr);
     __builtin_amdgcn_wave_barrier();
     SRT_STAMP(kb);
-    shadow_phase<COUNT, NQCAP, FILTER, RS>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
+    shadow_phase<COUNT, NQCAP, FILTER, RS, true, WIDE>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave);
 #ifdef SRT_DIAG
     SRT_STAMP(k1); diag_tile_record(rgb_linear, blockIdx.x, blockIdx.y, gridDim.x, k0, k1, ka, kb);
 #endif
@@ -1242,11 +1502,11 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     }
 }
 
-template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false, bool CAM = false>
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false, bool CAM = false, bool WIDE = true>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
-    trace_nq_body<COUNT, NQCAP, FILTER, RS, XCD_ROWS, ROOTS_AGAIN, false, CAM>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, counters);
+    trace_nq_body<COUNT, NQCAP, FILTER, RS, XCD_ROWS, ROOTS_AGAIN, false, CAM, WIDE>(s, p, hit_id, t_out, rgb_linear, rgb8, shadow_bits, counters);
 }
 // closest hit, shadow rays and shading of a frame in one launch (SHADE)
 template <int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false>
@@ -1271,6 +1531,7 @@ struct FrameItem {
     unsigned long long* shadow_bits; unsigned long long* counters; unsigned long long* counters_next; uint32_t* qcount;
     uint32_t* qlist; uint32_t qcap, pad_;      // the frame's quadrant list (8+-sample pipeline)
 };
+static_assert(sizeof(FrameItem) == sizeof(DevScene) + sizeof(DevParams) + 9 * 8 + 8, "FrameItem has no implicit padding");
 // the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)
 template <int NQCAP, bool FILTER>
 __global__ __launch_bounds__(256) void k_closest_hit_nq_batch(const FrameItem* __restrict__ items) {
@@ -1284,7 +1545,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq_batch(const FrameItem* _
     int32_t id; float t; V3 d;
     const bool roots_done = it.s.n_objects <= 32u;
     if (finish_background_tile<FILTER>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
-    closest_hit_phase<false, NQCAP, 2, 2, FILTER>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+    closest_hit_phase<false, NQCAP, 2, 2, FILTER, false, true>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave,
                                                   it.qcount, it.qlist, it.qcap, roots_done ? root_pass + wave * 16 : nullptr);
 }
@@ -1368,6 +1629,37 @@ __global__ __launch_bounds__(256) void k_resolve(DevParams p, const float* __res
         int q0 = quant1(tone1(a0, p.reinhard, p.gamma)), q1 = quant1(tone1(a1, p.reinhard, p.gamma)), q2 = quant1(tone1(a2, p.reinhard, p.gamma));
         if ((q0 | q1 | q2) == 0) { q0 = p.bg & 255; q1 = (p.bg >> 8) & 255; q2 = (p.bg >> 16) & 255; }
         rgb8[(size_t)i * 3] = (uint8_t)q0; rgb8[(size_t)i * 3 + 1] = (uint8_t)q1; rgb8[(size_t)i * 3 + 2] = (uint8_t)q2;
+    }
+}
+
+// =================================================================================================
+// The chip's VALU issue rate, measured (srt_debug_valu_rate): every wave runs `iters` x 64 v_fma_f32 over 16 independent accumulators
+// between two pairs of stamps (s_memtime = shader cycles, s_memrealtime = the constant 100 MHz counter all CUs share).  With 8 such waves
+// per SIMD the SIMDs issue back to back, so instructions / cycles per wave x 8 is what ONE SIMD issues per cycle -- the yardstick
+// bench.py's roofline prices VALU work against (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction over 2 cycles -> 0.5).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_valu_rate(uint32_t iters, float* __restrict__ sink, unsigned long long* __restrict__ stamps) {
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = (float)(threadIdx.x + k) * 1.0e-3f;
+    const float b = 0.99999f, c = 1.0e-7f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) sum += a[k];
+    sink[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        o[0] = t0; o[1] = t1; o[2] = r0; o[3] = r1;
     }
 }
 

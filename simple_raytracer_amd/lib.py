@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy", "srt_scene_update", "srt_scene_share",
                "srt_render_device", "srt_render_device_batch", "srt_render", "srt_render_async", "srt_host_alloc", "srt_host_free", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
                "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
-               "srt_debug_fail_host_allocs", "srt_scene_pipeline", "srt_scene_overlap_estimate")
+               "srt_debug_fail_host_allocs", "srt_debug_valu_rate", "srt_scene_pipeline", "srt_scene_overlap_estimate")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -241,6 +241,15 @@ def kat_interp_normal(in12, device=0):
     L = load(); in12 = _f(in12); n = in12.shape[0]; out = np.empty((n, 3), np.float32)
     _check(L.srt_kat_interp_normal(device, n, in12.ctypes.data_as(_f32p), out.ctypes.data_as(_f32p)), "srt_kat_interp_normal")
     return out
+
+
+def valu_rate(iters=2000, device=0):
+    """(wave-instructions per SIMD-cycle, shader clock in GHz, the same rate over the whole launch span): srt_debug_valu_rate."""
+    L = load()
+    out = (C.c_double * 3)()
+    L.srt_debug_valu_rate.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    _check(L.srt_debug_valu_rate(device, iters, out), "srt_debug_valu_rate")
+    return float(out[0]), float(out[1]), float(out[2])
 
 
 def kat_pow(x, y, device=0):

@@ -132,6 +132,16 @@ class FrameGather:
                     flat = self.recv[k][r].reshape(mine.shape[0], -1, C).index_select(1, self.src[r])
                     mine.view(mine.shape[0], -1, C).index_copy_(1, self.index[r], flat)
 
+    def wait_collective(self, k=0):
+        """Wait for slot k's collective only (the assembly stays to be done by finish): for per-phase clocks."""
+        if self.world > 1 and self.work[k] is not None:
+            self.work[k].wait()
+
+    def wait_assembly(self):
+        """Block the host until rank dst's assembly stream has drained (no-op elsewhere)."""
+        if self.asm_stream is not None:
+            self.asm_stream.synchronize()
+
     def finish_all(self):
         out = None
         for k in range(len(self.tiles)):

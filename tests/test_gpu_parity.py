@@ -474,7 +474,7 @@ def test_deep_soup_rows_match_oracle(srt, oracle):
     p = abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK, **kw)
     c = oracle.render(flat, p)
     assert c["hit_id"].shape[0] == 8 and (c["hit_id"] >= 0).mean() > 0.1
-    for variant in (0, 3, 6, 21, 22, 23, 24):
+    for variant in (0, 3, 6, 21, 22, 23, 24, 40, 41, 42):
         o = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8), **kw))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
@@ -511,6 +511,34 @@ def test_k5_soup_at_full_size_band(srt, oracle):
     for k in ("primary_rays", "hit_rays", "shadow_rays", "node_tests_primary", "tri_tests_primary", "node_tests_shadow", "tri_tests_shadow"):
         assert oc["stats"][k] == c["stats"][k], k
     assert c["stats"]["node_tests_primary"] / c["stats"]["primary_rays"] > 300       # hundreds of slab tests per ray: the boxes overlap heavily
+
+
+def test_k5_at_its_stated_size_whole_frame(srt, oracle):
+    """BASELINE configs[4] exactly as stated: 1,000,000 random triangles, 4096 x 4096, 256 spp -- ONE whole frame (4.3 G primary rays,
+    about six seconds) through the pipeline the library picks by itself, then a band of eight scanlines of that very frame against the
+    oracle at the same 256 spp: hit id and t of sub-sample 0 bit for bit, the averaged pre-tone-map colour within the tolerance, rgb8.
+    (spp is the labelled extension: the oracle restates its definition, the reference has none.)"""
+    import scenes
+    from simple_raytracer_amd import host
+    recipe, meshes = scenes.soup(1000000)
+    flat = host.build_flat_scene(recipe, meshes)
+    assert flat.n_tris == 1000000
+    ds = srt.DeviceScene(flat)
+    W = H = 4096
+    lights = abi.light_staircase(recipe.light, 1)
+    o = ds.render(abi.make_params(W, H, lights, spp=256))
+    assert ds.pipeline == "k_closest_hit_pk+k_shadow_nq+k_shade_tile"
+    st = o["stats"]
+    assert st["primary_rays"] == W * H * 256
+    assert st["shadow_rays"] == st["hit_rays"] and st["hit_rays"] > 0.3 * st["primary_rays"]
+    assert o["hit_id"].shape == (H, W)
+    y0 = 2048
+    c = oracle.render(flat, abi.make_params(W, H, lights, spp=256, block_rows=8, block_first=y0 // 8, block_stride=10 ** 6))
+    band = slice(y0, y0 + 8)
+    assert (c["hit_id"] >= 0).mean() > 0.3
+    assert np.array_equal(o["hit_id"][band], c["hit_id"]) and np.array_equal(bits(o["t"][band]), bits(c["t"]))
+    assert np.abs(o["rgb_linear"][band] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"][band], c["rgb8"], max_frac=1e-3)
 
 
 @pytest.mark.parametrize("name,W,H,L,spp", [("cubes4_a0", 128, 96, 3, 4), ("ground_bunny", 96, 54, 1, 9), ("texquad", 64, 48, 2, 16), ("cubes4_a0", 96, 64, 9, 4)])
@@ -567,7 +595,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 18, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 18, 20, 21, 22, 23, 24, 40, 41, 42, 43])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
@@ -586,6 +614,9 @@ def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
     d = ds.render(g.params(W, H, L))                      # shipped pipeline, non-counting build
     assert np.array_equal(d["hit_id"], o["hit_id"]) and np.array_equal(bits(d["t"]), bits(o["t"]))
     assert np.array_equal(bits(d["rgb_linear"]), bits(o["rgb_linear"])) and np.array_equal(d["rgb8"], o["rgb8"])
+    e = ds.render(g.params(W, H, L, flags=variant << 8))  # the variant's own non-counting build (40: the 32 B node records)
+    assert np.array_equal(e["hit_id"], o["hit_id"]) and np.array_equal(bits(e["t"]), bits(o["t"]))
+    assert np.array_equal(bits(e["rgb_linear"]), bits(o["rgb_linear"])) and np.array_equal(e["rgb8"], o["rgb8"])
 
 
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 190, 107, 1), ("cubes4_a0", 128, 96, 3), ("texquad", 64, 48, 2), ("cubes4_a40", 150, 100, 7),
@@ -785,12 +816,24 @@ def test_device_pow_against_library_and_host(srt):
     assert (bits(fast[sub]) != bits(host)).mean() < 3e-3 and np.abs(fast[sub] - host).max() < 1e-6
 
 
+def test_valu_issue_rate_is_the_guides(srt):
+    """The yardstick of bench.py's roofline, measured: independent v_fma_f32 streams at 8 waves per SIMD issue one wave64 instruction per
+    2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) -- 0.5 wave-instructions per SIMD-cycle, i.e. 1024 x 32 lane-operations per cycle
+    chip-wide (x 2 flop x 2.4 GHz = 157.3 TFLOP/s).  Not 0.25 (the SIMD-16 figure round 2 priced against)."""
+    per_simd, clock_ghz, span_rate = srt.valu_rate(2000)
+    assert 0.45 < per_simd <= 0.52, per_simd
+    assert 1.0 < clock_ghz < 2.6, clock_ghz
+    assert 0.35 < span_rate <= 0.52, span_rate
+
+
 def test_reference_object_manager_through_the_adapter(srt, oracle):
     """End to end with the reference's OWN data structures: its ObjectManager (compiled reference code, oracle/_ref) is
     filled by the scene recipe, then rendered twice -- by the reference's CPU path and, through the binding of
     INTEGRATION.md option A (oracle/srt_adapter.cpp -> include/srt.h), by the HIP kernels.  Same (px, py, rgb) list."""
     if not oracle.ref_adapter_available():
-        pytest.skip("oracle/_ref not built (it is built in the container that has the reference sources)")
+        # not a silent skip: the compiled reference is git-ignored and must TRAVEL with the snapshot (built by oracle/Makefile where
+        # /root/reference exists); without it this test -- the only one that runs the reference's own ObjectManager -- says so
+        pytest.xfail("oracle/_ref/libsrt_ref_adapter.so did not travel to this box: the reference-side adapter was NOT exercised")
     for name, (W, H) in (("cubes4_a40", (200, 150)), ("ground_bunny", (192, 108))):
         g = gu.GoldenScene(name)
         s = oracle.RefScene()
