@@ -592,8 +592,9 @@ class soup_workload:
 
 PMC_GROUPS = [["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"],
               # what the kernel waits for (roofline.limiter): wave-cycle split, then the vector-memory path
-              ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INST_LEVEL_VMEM"],
-              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TA_BUSY_avr"]]
+              ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"],
+              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TA_BUSY_avr"],
+              ["TCP_TCP_LATENCY_sum", "TCP_TA_TCP_STATE_READ_sum", "TD_TD_BUSY_sum", "TD_TC_STALL_sum"]]
 PMC_REQUIRED = 3        # the first three groups carry the roofline; a failed limiter pass only drops `limiter`
 
 
@@ -733,8 +734,10 @@ def limiter_block(c, cycles):
     out = {"wave_cycles_waiting_frac": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
            "wave_cycles_issue_stalled_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
            "wave_cycles_valu_frac": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
-           "wave_cycles_vmem_frac": round(c.get("SQ_ACTIVE_INST_VMEM", 0.0) / wc, 4),
+           "wave_cycles_scalar_frac": round(c.get("SQ_ACTIVE_INST_SCA", 0.0) / wc, 4),
            "wave_cycles_lds_frac": round(c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4)}
+    if c.get("SQ_INSTS_VMEM_RD"):
+        out["vmem_read_wave_insts"] = int(c["SQ_INSTS_VMEM_RD"])
     cu_cycles = 256.0 * cycles
     if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") is not None and cu_cycles:
         out["l1_tag_lookups_per_cu_cycle"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / cu_cycles, 4)
@@ -744,8 +747,10 @@ def limiter_block(c, cycles):
         out["l1_pending_on_l2_stall_frac"] = round(c["TCP_PENDING_STALL_CYCLES_sum"] / cu_cycles, 4)
     if c.get("TCP_TCP_TA_DATA_STALL_CYCLES_sum") is not None and cu_cycles:
         out["l1_data_return_stall_frac"] = round(c["TCP_TCP_TA_DATA_STALL_CYCLES_sum"] / cu_cycles, 4)
-    if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_INST_LEVEL_VMEM"):
-        out["vmem_latency_cycles"] = round(c["SQ_INST_LEVEL_VMEM"] / c["SQ_INSTS_VMEM_RD"], 1)
+    if c.get("TCP_TCP_LATENCY_sum") and c.get("TCP_TA_TCP_STATE_READ_sum"):
+        out["l1_latency_cycles_per_wave_inst"] = round(c["TCP_TCP_LATENCY_sum"] / c["TCP_TA_TCP_STATE_READ_sum"], 1)
+    if c.get("TD_TC_STALL_sum") is not None and cu_cycles:
+        out["td_waiting_for_l1_data_frac"] = round(c["TD_TC_STALL_sum"] / cu_cycles, 4)
     w = out["wave_cycles_waiting_frac"]
     if w >= 0.5:
         out["name"] = "latency: waves parked behind s_waitcnt (vector-memory gathers of node / triangle records through the L1) most of their life"

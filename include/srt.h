@@ -257,7 +257,7 @@ int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, fl
 /* Measurement hook: the chip's VALU issue rate from independent v_fma_f32 streams at 8 waves per SIMD (the yardstick bench.py's
  * roofline prices the kernels' VALU work against).  out[0] = wave-instructions one SIMD issues per cycle (MI355X: SIMD-32, a wave64
  * instruction over 2 cycles -> 0.5), out[1] = shader clock in GHz during the run, out[2] = the same rate over the whole launch span. */
-int srt_debug_valu_rate(int device, uint32_t iters, double* out3);
+int srt_debug_valu_rate(int device, uint32_t iters, double* out4);      /* out[3] = waves that shared a SIMD (median) */
 
 /* Test hook: the next n host allocations made on behalf of a caller fail (std::bad_alloc inside the library), so that
  * the SRT_ERR_OOM path can be exercised without exhausting memory.  Not for production use. */

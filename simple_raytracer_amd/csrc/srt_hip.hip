@@ -12,6 +12,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <new>
 #include <thread>
@@ -633,7 +634,7 @@ static inline uint32_t variant_of(const srt_params* p) { return (p->flags >> 8) 
 
 static int check_params(const srt_params* p) {
     if (!p || !p->width || !p->height || !p->block_rows || !p->block_stride) return SRT_ERR_ARG;
-    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22 && ((p->flags >> 8) & 0xffu) != 35 && ((p->flags >> 8) & 0xffu) != 41)) return SRT_ERR_ARG;      // camera mode: shipped pipelines only
+    if (p->ray_matrix && (((p->flags >> 8) & 0xffu) != 0 && ((p->flags >> 8) & 0xffu) != 22 && ((p->flags >> 8) & 0xffu) != 35)) return SRT_ERR_ARG;      // camera mode: shipped pipelines only
     if (p->n_lights && !p->light_pos) return SRT_ERR_ARG;
     if (p->block_cols && ((p->block_cols & 7u) || (p->block_rows & 7u) || p->block_first >= p->block_stride)) return SRT_ERR_ARG;   // tiles of whole 8x8 pixel blocks
     if (p->spp < 1 || p->spp > 4096) return SRT_ERR_ARG;
@@ -732,12 +733,13 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     uint32_t variant = (p->flags >> 8) & 0xffu;            // experimental kernel selector (0 = shipped pipeline)
     const bool force_nq = variant == 24;                   // 24: what variant 0 does for a scene WITHOUT the packet preference (A/B on soups)
     const bool coarse_grid = variant == 27;                // 27: variant 0 with 2 x 2 tiles per workgroup in the unfused closest-hit launch (A/B, not shipped)
-    const bool narrow = variant == 40 || variant == 42;    // 40: variant 0 with the node-queue kernels on the 32 B node records (a queue entry = a node still to be tested: the round-2 form, A/B)
-    dp.exp = (variant == 41 || variant == 42 || variant == 43) ? 1u : 0u;   // 41 / 42: variants 0 / 40 with the node queues kept in node-major order (A/B); 43: 41 built for 5 waves per SIMD
+    // 40: the round-2 form everywhere (32 B node records, queue pushes in lane order); 41 / 42: the 64 B / the 32 B records in every
+    // node-queue kernel (node-major order); 43: the shipped kernels with pushes in lane order.  Shipped (0): node-major order; 32 B records
+    // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
+    const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
+    dp.exp = (variant == 40 || variant == 43) ? 1u : 0u;
     dp.pad2_ = 0u;
-    const bool wide5 = variant == 43;
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || narrow || variant == 41) variant = 0;
-    if (wide5) variant = 11;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 43)) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -849,7 +851,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 12) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // round-1 form: roots re-tested per wave (A/B)
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
-                else if (narrow)        hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, false, false, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else if (all_wide)      hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, false, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
             } else if (bc && !count && (p->flags >> 8 & 0xffu) == 0 && pk_shadow && !pk_closest && spp == 1 && bc->accepts(wl, rows)) {
@@ -866,8 +868,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // dispatch-bound, and a workgroup that walks its live tiles one after the other is a longer tail
                 hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, true>), dim3((grid8.x + 1) / 2, (grid8.y + 1) / 2), block, 0, stream,
                                    s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
-            } else if (narrow && !count) {
-                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
+            } else if (all_wide && !count) {
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }
@@ -892,7 +894,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (narrow)       hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
+            else if (all_narrow)   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
             else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);      // 80 VGPRs: six waves per SIMD (86 without the bound: five)
             HIP_TRY(hipGetLastError());
         }
@@ -1247,9 +1249,11 @@ int srt_kat_pow(int device, uint32_t n, const float* x, const float* y, float* f
     return o2.down(lib, (size_t)n * 4);
 }
 
-// out[0] = VALU wave-instructions one SIMD issues per cycle (median over waves of 64 * iters / cycles, x the 8 waves that share a
-// SIMD), out[1] = shader clock in GHz during the run (s_memtime against the 100 MHz s_memrealtime), out[2] = the same rate from the
-// chip-wide span (all waves' instructions / (1024 SIMDs x clock x (last end - first start))), which includes launch ramp and tail.
+// out[0] = VALU wave-instructions one SIMD issues per cycle: per SIMD (XCC / SE / SH / CU / SIMD of HW_ID), the instructions of the
+// waves that ran on it over the cycles from its first wave's start to its last wave's end (s_memtime), median over the SIMDs;
+// out[1] = shader clock in GHz during the run (s_memtime against the 100 MHz s_memrealtime); out[2] = the same rate from the
+// chip-wide span (all waves' instructions / (SIMDs x clock x (last end - first start))), which includes launch ramp and tail;
+// out[3] = waves per SIMD (median) that shared a SIMD during the run.
 int srt_debug_valu_rate(int device, uint32_t iters, double* out) {
     if (!iters || !out) return SRT_ERR_ARG;
     return guarded([&]() -> int {
@@ -1259,28 +1263,37 @@ int srt_debug_valu_rate(int device, uint32_t iters, double* out) {
     const uint32_t n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     const uint32_t wgs = n_cu * 8u;                            // 8 workgroups of 4 waves per CU = 8 waves per SIMD, all resident
     DevBuf sink, st;
-    KAT_TRY(sink.alloc((size_t)wgs * 256 * 4)); KAT_TRY(st.alloc((size_t)wgs * 4 * 4 * 8));
+    KAT_TRY(sink.alloc((size_t)wgs * 256 * 4)); KAT_TRY(st.alloc((size_t)wgs * 4 * 8 * 8));
     for (int rep = 0; rep < 2; rep++) {                        // the first launch warms the clock
         hipLaunchKernelGGL(k_valu_rate, dim3(wgs), dim3(256), 0, 0, iters, (float*)sink.p, (unsigned long long*)st.p);
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     }
-    std::vector<unsigned long long> h((size_t)wgs * 16);
+    std::vector<unsigned long long> h((size_t)wgs * 32);
     KAT_TRY(st.down(h.data(), h.size() * 8));
     const size_t nw = (size_t)wgs * 4;
-    std::vector<double> per_wave(nw), clk(nw);
+    std::vector<double> clk(nw);
     unsigned long long rmin = ~0ull, rmax = 0;
+    struct Simd { unsigned long long t0 = ~0ull, t1 = 0; uint32_t waves = 0; };
+    std::map<unsigned long long, Simd> simds;
     for (size_t w = 0; w < nw; w++) {
-        const unsigned long long t0 = h[4 * w], t1 = h[4 * w + 1], r0 = h[4 * w + 2], r1 = h[4 * w + 3];
-        per_wave[w] = 64.0 * iters / (double)(t1 - t0);
+        const unsigned long long t0 = h[8 * w], t1 = h[8 * w + 1], r0 = h[8 * w + 2], r1 = h[8 * w + 3], where = h[8 * w + 4];
         clk[w] = (double)(t1 - t0) / (double)(r1 - r0) * 0.1;      // GHz: ticks per 10 ns
         if (r0 < rmin) rmin = r0;
         if (r1 > rmax) rmax = r1;
+        Simd& sd = simds[((where >> 32) & 0xfull) << 16 | (where & 0x7f30ull)];      // XCC | SE, SH, CU, SIMD bits of HW_ID
+        if (t0 < sd.t0) sd.t0 = t0;
+        if (t1 > sd.t1) sd.t1 = t1;
+        sd.waves++;
     }
-    std::nth_element(per_wave.begin(), per_wave.begin() + nw / 2, per_wave.end());
+    std::vector<double> rate, share;
+    for (const auto& kv : simds) { rate.push_back(64.0 * iters * kv.second.waves / (double)(kv.second.t1 - kv.second.t0)); share.push_back((double)kv.second.waves); }
+    std::nth_element(rate.begin(), rate.begin() + rate.size() / 2, rate.end());
+    std::nth_element(share.begin(), share.begin() + share.size() / 2, share.end());
     std::nth_element(clk.begin(), clk.begin() + nw / 2, clk.end());
-    out[0] = per_wave[nw / 2] * 8.0;
+    out[0] = rate[rate.size() / 2];
     out[1] = clk[nw / 2];
-    out[2] = (64.0 * iters * (double)nw) / ((double)n_cu * 4.0 * out[1] * 1e9 * ((double)(rmax - rmin) * 1e-8));
+    out[2] = (64.0 * iters * (double)nw) / ((double)simds.size() * out[1] * 1e9 * ((double)(rmax - rmin) * 1e-8));
+    out[3] = share[share.size() / 2];
     return SRT_OK;
     });
 }

@@ -51,7 +51,7 @@ struct DevParams {
     uint32_t shadow_px_major;     // shadow bits as the packet shadow kernel writes them: per pixel one u64 per 64 light samples
     uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
     float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
-    uint32_t exp, pad2_;          // experiment switches (A/B variants, wave-uniform branches): bit 0 = node-major queue order
+    uint32_t exp, pad2_;          // experiment switches (A/B variants, wave-uniform branches): bit 0 = queue pushes in LANE order (the round-2 form) instead of node-major
 };
 static_assert(sizeof(DevParams) == 152, "DevParams has no implicit padding");
 
@@ -450,7 +450,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         const unsigned long long ma = __ballot(leaf_a), mb = __ballot(leaf_b);
         if (ma | mb) {
             uint32_t pos = tqn + lane_prefix(ma) + lane_prefix(mb), q = pos + (leaf_a ? 1u : 0u);
-            if (p.exp & 1u) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
+            if (!(p.exp & 1u)) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
             if (leaf_a) { tq[2 * pos] = info_a; tq[2 * pos + 1] = pl; }
             if (leaf_b) { tq[2 * q] = info_b; tq[2 * q + 1] = pl; }
             tqn += (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
@@ -536,7 +536,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             const unsigned long long ml = __ballot(in_l), mr = __ballot(in_r);
             const uint32_t n_in = (uint32_t)__popcll(ml) + (uint32_t)__popcll(mr);
             if (nqn + n_in <= (uint32_t)NQCAP) {
-                if (p.exp & 1u) {      // node-major: all right children, then all left children -- rays that visit one node stay neighbours
+                if (!(p.exp & 1u)) {      // node-major: all right children, then all left children -- rays that visit one node stay neighbours
                     if (in_r) nq[nqn + lane_prefix(mr)] = ((uint32_t)(~rinfo) << 6) | pl;
                     if (in_l) nq[nqn + (uint32_t)__popcll(mr) + lane_prefix(ml)] = ((uint32_t)(~linfo) << 6) | pl;
                 } else {
@@ -601,7 +601,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                 const unsigned long long im = __ballot(inner);
                 if (inner) {
                     uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
-                    if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + (uint32_t)__popcll(im); }      // node-major
+                    if (!(p.exp & 1u)) { pos = nqn + lane_prefix(im); pos1 = pos + (uint32_t)__popcll(im); }      // node-major
                     nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
                     nq[pos1] = ((uint32_t)(root + 1) << 6) | pl;      // left child on top: popped first
                 }
@@ -669,7 +669,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
                 if (inner) {
                     uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
-                    if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }      // node-major
+                    if (!(p.exp & 1u)) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }      // node-major
                     nq[pos] = ((uint32_t)(~info) << 6) | pl;          // right child
                     nq[pos1] = ((uint32_t)(node + 1) << 6) | pl;      // left child on top: popped first
                 }
@@ -826,7 +826,7 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
 // then work through the live tiles one after the other (four waves per tile, as ever).  For frames that are mostly background
 // (3840x2160 of the reference's scenes: 94 % of 129,600 tiles) the launch is bound by workgroup dispatch, and this is a quarter
 // of the workgroups; the host picks it for big frames only (a frame full of geometry keeps the finer grid's balance).
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false, bool WIDE = true>
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
                                                         uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         const unsigned long long ma = __ballot(leaf_a), mb = __ballot(leaf_b);
         if (ma | mb) {
             uint32_t pos = tqn + lane_prefix(ma) + lane_prefix(mb), q = pos + (leaf_a ? 1u : 0u);
-            if (p.exp & 1u) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
+            if (!(p.exp & 1u)) { pos = tqn + lane_prefix(ma); q = tqn + (uint32_t)__popcll(ma) + lane_prefix(mb); }      // node-major
             if (leaf_a) { tq[2 * pos] = info_a; tq[2 * pos + 1] = rs; }
             if (leaf_b) { tq[2 * q] = info_b; tq[2 * q + 1] = rs; }
             tqn += (uint32_t)__popcll(ma) + (uint32_t)__popcll(mb);
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                         const unsigned long long ml = __ballot(in_l), mr = __ballot(in_r);
                         const uint32_t n_in = (uint32_t)__popcll(ml) + (uint32_t)__popcll(mr);
                         if (nqn + n_in <= (uint32_t)NQCAP) {
-                            if (p.exp & 1u) {
+                            if (!(p.exp & 1u)) {
                                 if (in_r) nq[nqn + lane_prefix(mr)] = ((uint32_t)(~rinfo) << 6) | rs;
                                 if (in_l) nq[nqn + (uint32_t)__popcll(mr) + lane_prefix(ml)] = ((uint32_t)(~linfo) << 6) | rs;
                             } else {
@@ -1306,7 +1306,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                         if (nqn + 2 * n_in <= (uint32_t)NQCAP) {
                             if (inner) {
                                 uint32_t pos = nqn + 2 * lane_prefix(im), pos1 = pos + 1;
-                                if (p.exp & 1u) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }
+                                if (!(p.exp & 1u)) { pos = nqn + lane_prefix(im); pos1 = pos + n_in; }
                                 nq[pos] = ((uint32_t)(~info) << 6) | rs;
                                 nq[pos1] = ((uint32_t)(node + 1) << 6) | rs;
                             }
@@ -1435,7 +1435,10 @@ __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevPara
 // in LDS (its shadow masks are there already) and bumps an LDS counter, and the wave that finds the other three done shades the
 // tile's 64 pixels, one per lane -- what k_shade_tile does in a second launch from hit ids, t and shadow words re-read from
 // memory.  Up to 63 light samples (one group of masks); `shadow_bits` may be null then (nobody reads the words).
-template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false, bool WIDE = true>
+// WIDE (the 64 B inner-node records): measured per kernel -- the stand-alone shadow kernel, whose rays cross a
+// soup's overlapping boxes hundreds of nodes deep, gains 10 % from it; the fused kernel and the closest-hit kernel, whose frames are
+// mostly short waves, lose 5 % (16 VGPRs of record per lane instead of 8: spills at six waves per SIMD), so they keep the 32 B records.
+template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false, bool WIDE = false>
 __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                               float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                               unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
@@ -1502,7 +1505,7 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     }
 }
 
-template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false, bool CAM = false, bool WIDE = true>
+template <bool COUNT, int NQCAP, bool FILTER, int MINW, int RS, bool XCD_ROWS = false, bool ROOTS_AGAIN = false, bool CAM = false, bool WIDE = false>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                                   float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                   unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters) {
@@ -1545,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_nq_batch(const FrameItem* _
     int32_t id; float t; V3 d;
     const bool roots_done = it.s.n_objects <= 32u;
     if (finish_background_tile<FILTER>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
-    closest_hit_phase<false, NQCAP, 2, 2, FILTER, false, true>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
+    closest_hit_phase<false, NQCAP, 2, 2, FILTER, false, false>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
                                                   it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave,
                                                   it.qcount, it.qlist, it.qcap, roots_done ? root_pass + wave * 16 : nullptr);
 }
@@ -1634,9 +1637,10 @@ __global__ __launch_bounds__(256) void k_resolve(DevParams p, const float* __res
 
 // =================================================================================================
 // The chip's VALU issue rate, measured (srt_debug_valu_rate): every wave runs `iters` x 64 v_fma_f32 over 16 independent accumulators
-// between two pairs of stamps (s_memtime = shader cycles, s_memrealtime = the constant 100 MHz counter all CUs share).  With 8 such waves
-// per SIMD the SIMDs issue back to back, so instructions / cycles per wave x 8 is what ONE SIMD issues per cycle -- the yardstick
-// bench.py's roofline prices VALU work against (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction over 2 cycles -> 0.5).
+// between two pairs of stamps (s_memtime = shader cycles, s_memrealtime = the constant 100 MHz counter all CUs share) and notes the
+// SIMD it ran on.  With several such waves per SIMD the SIMDs issue back to back, so a SIMD's instructions over the cycles between its
+// first wave's start and its last wave's end is what ONE SIMD issues per cycle -- the yardstick bench.py's roofline prices VALU work
+// against (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction over 2 cycles -> 0.5; measured: 0.45).
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_valu_rate(uint32_t iters, float* __restrict__ sink, unsigned long long* __restrict__ stamps) {
     float a[16];
@@ -1657,9 +1661,10 @@ __global__ __launch_bounds__(256) void k_valu_rate(uint32_t iters, float* __rest
 #pragma unroll
     for (int k = 0; k < 16; k++) sum += a[k];
     sink[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if ((threadIdx.x & 63) == 0) {      // + where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
         o[0] = t0; o[1] = t1; o[2] = r0; o[3] = r1;
+        o[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
     }
 }
 

@@ -244,12 +244,12 @@ def kat_interp_normal(in12, device=0):
 
 
 def valu_rate(iters=2000, device=0):
-    """(wave-instructions per SIMD-cycle, shader clock in GHz, the same rate over the whole launch span): srt_debug_valu_rate."""
+    """(wave-instructions per SIMD-cycle, shader clock in GHz, the same rate over the whole launch span, waves per SIMD): srt_debug_valu_rate."""
     L = load()
-    out = (C.c_double * 3)()
+    out = (C.c_double * 4)()
     L.srt_debug_valu_rate.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     _check(L.srt_debug_valu_rate(device, iters, out), "srt_debug_valu_rate")
-    return float(out[0]), float(out[1]), float(out[2])
+    return float(out[0]), float(out[1]), float(out[2]), float(out[3])
 
 
 def kat_pow(x, y, device=0):

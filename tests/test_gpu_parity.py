@@ -380,6 +380,44 @@ def test_textured_asset_from_files_through_the_loader_to_hip(srt, oracle, tmp_pa
     check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
 
 
+def test_scene_update_with_other_texture_images(srt, oracle):
+    """A second scene with the SAME counts but other pictures through one device scene (what a renderer that keeps its scene does
+    with a caller's next ObjectManager): srt_scene_update compares the texture table and the images' content hash, uploads changed
+    images again, and refuses another table (other sizes) -- never the first scene's texels under the second scene's triangles."""
+    import dataclasses
+    g, _ = device_scene(srt, "texquad")
+    a = g.flat
+    assert a.n_textures >= 1 and (a.tri_tex >= 0).any()
+    W, H = 120, 90
+    p = abi.make_params(W, H, abi.light_staircase(g.light, 1))
+    ds = srt.DeviceScene(a)
+    first = ds.render(p)
+    other = (255 - a.tex_rgb.astype(np.int32)).astype(np.uint8)          # same sizes, other pixels
+    other[::7] = 13
+    b = dataclasses.replace(a, tex_rgb=other)
+    ds.update(b)
+    o = ds.render(p)
+    c = oracle.render(b, p)
+    assert np.array_equal(o["hit_id"], c["hit_id"]) and np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
+    check_rgb8(o["rgb8"], c["rgb8"])
+    assert not np.array_equal(o["rgb8"], first["rgb8"]), "the second scene's pictures must show"
+    fresh = srt.DeviceScene(b).render(p)
+    assert np.array_equal(bits(o["rgb_linear"]), bits(fresh["rgb_linear"])) and np.array_equal(o["rgb8"], fresh["rgb8"])
+    ds.update(a)                                                          # and back: unchanged bytes of a are uploaded again because b's are on the device
+    assert np.array_equal(ds.render(p)["rgb8"], first["rgb8"])
+    ds.update(a)                                                          # same images: nothing to upload, same picture
+    assert np.array_equal(ds.render(p)["rgb8"], first["rgb8"])
+    # another texture table (the image reinterpreted with width and height swapped): refused, nothing written
+    if int(a.tex_w[0]) != int(a.tex_h[0]):
+        t = dataclasses.replace(a, tex_w=a.tex_h.copy(), tex_h=a.tex_w.copy())
+    else:
+        t = dataclasses.replace(a, tex_w=(a.tex_w // 2).astype(np.uint32), tex_h=(a.tex_h * 2).astype(np.uint32))
+    with pytest.raises(srt.SrtError) as e:
+        ds.update(t)
+    assert e.value.code == abi.SRT_ERR_LAYOUT
+    assert np.array_equal(ds.render(p)["rgb8"], first["rgb8"])
+
+
 def test_renderer_keeps_the_scene_across_frames(srt, oracle):
     """srt_host::Renderer (what the drop-in sendRaysAndIntersectPointsColors runs on): a small orbit through render(), through
     submit() / collect() with the next frame built in between, and through camera mode; every frame against the oracle."""
@@ -474,7 +512,7 @@ def test_deep_soup_rows_match_oracle(srt, oracle):
     p = abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK, **kw)
     c = oracle.render(flat, p)
     assert c["hit_id"].shape[0] == 8 and (c["hit_id"] >= 0).mean() > 0.1
-    for variant in (0, 3, 6, 21, 22, 23, 24, 40, 41, 42):
+    for variant in (0, 3, 6, 21, 22, 23, 24, 40, 41, 42, 43):
         o = ds.render(abi.make_params(1024, 1024, abi.light_staircase(recipe.light, 1), flags=abi.SRT_FLAG_COUNT_WORK | (variant << 8), **kw))
         assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
         assert np.abs(o["rgb_linear"] - c["rgb_linear"]).max() < TOL_LINEAR
@@ -820,8 +858,9 @@ def test_valu_issue_rate_is_the_guides(srt):
     """The yardstick of bench.py's roofline, measured: independent v_fma_f32 streams at 8 waves per SIMD issue one wave64 instruction per
     2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) -- 0.5 wave-instructions per SIMD-cycle, i.e. 1024 x 32 lane-operations per cycle
     chip-wide (x 2 flop x 2.4 GHz = 157.3 TFLOP/s).  Not 0.25 (the SIMD-16 figure round 2 priced against)."""
-    per_simd, clock_ghz, span_rate = srt.valu_rate(2000)
-    assert 0.45 < per_simd <= 0.52, per_simd
+    per_simd, clock_ghz, span_rate, waves_per_simd = srt.valu_rate(2000)
+    assert waves_per_simd >= 4, waves_per_simd
+    assert 0.42 < per_simd <= 0.52, (per_simd, clock_ghz, span_rate, waves_per_simd)      # measured: 0.451 .. 0.453
     assert 1.0 < clock_ghz < 2.6, clock_ghz
     assert 0.35 < span_rate <= 0.52, span_rate
 
