@@ -271,7 +271,19 @@ __device__ __forceinline__ float pow_like_host(float xf, float yf) {
     return (float)pow((double)xf, (double)yf);                // zeros, denormals, infinities, NaN, negative bases, huge exponents
 }
 
+// x^e for a small integer exponent, e in [1, 64]: the square-and-multiply branch of pow_like_host on its own.  For such an exponent it IS
+// pow_like_host on every x >= 0 (and NaN, -0): below 1e-30, where pow_like_host calls the library, x^e is x itself (e = 1) or underflows
+// to a zero in binary32 either way, and the f64 products cannot overflow before the cast does.  A kernel that only ever shades with
+// such exponents (the reference's default shininess is 15, Object.cpp:33) carries none of the general path's registers.
+__device__ __forceinline__ float pow_small_int(float xf, uint32_t e) {
+    double r = 1.0, b = (double)xf;
+    for (; e; e >>= 1) { if (e & 1u) r *= b; b *= b; }
+    return (float)r;
+}
+
 // ---- a8: phongIllumination :144-200, lightColor = (1,1,1) (:433) ---------------------------------
+// INT_SHIN: the caller guarantees an integer shininess in [1, 64] (checked on the host for every object of the scene)
+template <bool INT_SHIN = false>
 __device__ __forceinline__ V3 phong(V3 n, V3 o, V3 d, V3 L, V3 objColor, float ka, float ks, float shin, float t) {
     const float rView = 1.0f / 3.14159265358979323846264338327950288f;
     const float lc = 1.0f;
@@ -287,7 +299,8 @@ __device__ __forceinline__ V3 phong(V3 n, V3 o, V3 d, V3 L, V3 objColor, float k
     V3 I = neg(l);
     float ndi = dot3(n, I);
     V3 r = mk(I.x - (n.x * ndi) * 2.0f, I.y - (n.y * ndi) * 2.0f, I.z - (n.z * ndi) * 2.0f);
-    float sp = pow_like_host(glm_max(dot3(r, v), 0.0f), shin);
+    const float sx = glm_max(dot3(r, v), 0.0f);
+    float sp = INT_SHIN ? pow_small_int(sx, (uint32_t)shin) : pow_like_host(sx, shin);
     float s1 = ((lc * ks) * m) * sp;
     return mk((diffuse.x + s1) + ambient.x, (diffuse.y + s1) + ambient.y, (diffuse.z + s1) + ambient.z);
 }

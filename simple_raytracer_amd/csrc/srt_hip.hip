@@ -63,6 +63,7 @@ struct SceneRecords {
     uint64_t tex_bytes = 0, tex_hash = 0;                                    // ... and the size and content hash of the uploaded images
     double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
     bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
+    bool int_shin = false;           // every object's shininess is an integer in [1, 64]: the shading kernel without the general pow
     ~SceneRecords() { (void)hipSetDevice(device); for (void* d : allocs) (void)hipFree(d); }
 };
 
@@ -412,6 +413,14 @@ static void derive_tri_first(const srt_scene_desc* d, int32_t* first) {
     for (uint32_t k = d->n_objects; k-- > 0;) if (first[k] > first[k + 1]) first[k] = first[k + 1];      // objects without triangles
 }
 
+static bool all_integer_shininess(const srt_scene_desc* d) {
+    for (uint32_t k = 0; k < d->n_objects; k++) {
+        const float sh = d->obj_material[3 * (size_t)k + 2];
+        if (!(sh >= 1.0f && sh <= 64.0f && sh == std::trunc(sh))) return false;
+    }
+    return true;
+}
+
 static int check_desc(const srt_scene_desc* d) {
     if (!d->n_objects || !d->n_nodes || !d->node_min || !d->node_max || !d->node_left || !d->node_right ||
         !d->node_first || !d->node_count || !d->obj_root || !d->obj_color || !d->obj_material) return SRT_ERR_ARG;
@@ -470,6 +479,11 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     UP(upload(s, nodes.data(), nodes.size(), &s->dev.nodes));
     UP(upload(s, wide.data(), wide.size(), &s->dev.wide));
     UP(upload(s, root_info.data(), root_info.size(), &s->dev.obj_root_info));
+    {
+        std::vector<DevNode> roots(d->n_objects);
+        for (uint32_t k = 0; k < d->n_objects; k++) roots[k] = nodes[ranges[k].x];
+        UP(upload(s, roots.data(), roots.size(), &s->dev.root_nodes));
+    }
     UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
     UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
     UP(upload(s, d->tri_obj, d->n_tris, &s->dev.tri_obj));
@@ -508,6 +522,7 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     s->n_textures = d->n_textures; s->has_tex = any_tex;
     s->rec->overlap = overlap;
     s->rec->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
+    s->rec->int_shin = all_integer_shininess(d);
     const hipError_t e = init_handle_state(s);
     if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
     *out = s;
@@ -576,7 +591,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
                  o_triobj = o_triso + pad(nT * sizeof(DevTriO)), o_ranges = o_triobj + pad(nT * 4), o_first = o_ranges + pad(nO * sizeof(int2)),
                  o_color = o_first + pad((nO + 1) * 4), o_mat = o_color + pad(nO * 12), o_nrm = o_mat + pad(nO * 12),
                  o_tex = o_nrm + pad(d->tri_normals ? nT * 36 : 0), o_tc = o_tex + pad(any_tex ? nT * 4 : 0), o_wide = o_tc + pad(any_tex ? nT * 24 : 0),
-                 o_rinfo = o_wide + pad(nW * sizeof(DevWide)), o_widx = o_rinfo + pad(nO * 4), o_img = o_widx + pad(nN * 4),
+                 o_rinfo = o_wide + pad(nW * sizeof(DevWide)), o_widx = o_rinfo + pad(nO * 4), o_roots = o_widx + pad(nN * 4), o_img = o_roots + pad(nO * sizeof(DevNode)),
                  total = o_img + pad(tex_changed ? tex_total : 0);
     if (s->stage_bytes < total) {
         if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
@@ -591,6 +606,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     rc = build_device_records(d, nodes, ranges);
     if (rc != SRT_OK) return rc;
     build_wide_records(nodes, d->n_nodes, ranges, d->n_objects, (DevWide*)(h + o_wide), (int32_t*)(h + o_rinfo), (int32_t*)(h + o_widx));
+    for (uint32_t k = 0; k < d->n_objects; k++) ((DevNode*)(h + o_roots))[k] = nodes[ranges[k].x];
     if (tex_changed) std::memcpy(h + o_img, d->tex_rgb, tex_total);
     derive_triangles(d, (DevTri*)(h + o_tris), (DevTriO*)(h + o_triso));
     derive_tri_first(d, (int32_t*)(h + o_first));
@@ -603,6 +619,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     CP(s->dev.nodes, o_nodes, nN * sizeof(DevNode));
     CP(s->dev.wide, o_wide, nW * sizeof(DevWide));
     CP(s->dev.obj_root_info, o_rinfo, nO * 4);
+    CP(s->dev.root_nodes, o_roots, nO * sizeof(DevNode));
     if (tex_changed) { CP(s->dev.tex, o_img, tex_total); s->rec->tex_hash = tex_hash_new; }
     CP(s->dev.tris, o_tris, nT * sizeof(DevTri));
     CP(s->dev.tris_o, o_triso, nT * sizeof(DevTriO));
@@ -617,6 +634,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     HIP_TRY(hipEventRecord(s->staged, stream));
     s->rec->overlap = overlap_estimate(nodes, d->n_nodes, ranges, d->n_objects);
     s->rec->prefer_packet = s->rec->overlap > PACKET_OVERLAP_THRESHOLD;
+    s->rec->int_shin = all_integer_shininess(d);
     return SRT_OK;
 }
 
@@ -737,9 +755,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // node-queue kernel (node-major order); 43: the shipped kernels with pushes in lane order.  Shipped (0): node-major order; 32 B records
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
-    dp.exp = (variant == 40 || variant == 43) ? 1u : 0u;
+    dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u);      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.pad2_ = 0u;
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 43)) variant = 0;            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 45)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -904,7 +922,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (shaded) { std::snprintf(s->pipeline, sizeof(s->pipeline), "k_trace_shade_nq"); return SRT_OK; }
         DevParams sp = fp;
         sp.shadow_px_major = pk_shadow ? 1u : 0u;
-        hipLaunchKernelGGL(k_shade_tile, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
+        if (s->rec->int_shin && variant_of(p) != 44) hipLaunchKernelGGL(k_shade_tile<1>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
+        else                                         hipLaunchKernelGGL(k_shade_tile<0>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);      // (44: the general form forced, A/B)
         HIP_TRY(hipGetLastError());
         return SRT_OK;
     };
@@ -1011,6 +1030,8 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         if ((params[i].flags & SRT_FLAG_SMOOTH_NORMALS) && (!scenes[i]->dev.tri_normals || variant_of(&params[i]) == 1)) return SRT_ERR_ARG;
     }
     hipStream_t stream = (hipStream_t)stream_;
+    bool batch_int_shin = true;                               // the specialised shading kernel only if every scene of the batch qualifies
+    for (uint32_t i = 0; i < n; i++) batch_int_shin = batch_int_shin && scenes[i]->rec->int_shin;
     BatchCollector bc;
     for (uint32_t i = 0; i < n; i++) {
         const int rc = render_device_impl(scenes[i], &params[i], stream_, d_hit_id ? d_hit_id[i] : nullptr, d_t ? d_t[i] : nullptr,
@@ -1029,14 +1050,15 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         if (rc == SRT_OK && table) {
             hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true>), g8, block, 0, stream, table);
             hipLaunchKernelGGL((k_shadow_pk_batch<true>), dim3(wgs, (uint32_t)held_pk), block, 0, stream, table);
-            hipLaunchKernelGGL(k_shade_tile_batch, g16, block, 0, stream, table);
+            if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g16, block, 0, stream, table);
+            else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g16, block, 0, stream, table);
             if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
         } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
             const uint32_t wgs1 = (uint32_t)(max_units / 4 + 1 < wgs_all ? max_units / 4 + 1 : wgs_all);
             for (const FrameItem& it : bc.items_pk) {
                 hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true>), dim3(g8.x, g8.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, it.qcount, it.qlist, it.qcap);
                 hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs1), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
-                hipLaunchKernelGGL(k_shade_tile, dim3(g16.x, g16.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+                hipLaunchKernelGGL(k_shade_tile<0>, dim3(g16.x, g16.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
                 if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
             }
         }
@@ -1051,13 +1073,14 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         hipLaunchKernelGGL((k_trace_nq_batch<512, true, 6, 16>), g_trace, block, 0, stream, table);
         if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
         if (rc == SRT_OK) {
-            hipLaunchKernelGGL(k_shade_tile_batch, g_shade, block, 0, stream, table);
+            if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g_shade, block, 0, stream, table);
+            else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g_shade, block, 0, stream, table);
             if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
         }
     } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
         for (const FrameItem& it : bc.items) {
             hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), dim3(g_trace.x, g_trace.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
-            hipLaunchKernelGGL(k_shade_tile, dim3(g_shade.x, g_shade.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+            hipLaunchKernelGGL(k_shade_tile<0>, dim3(g_shade.x, g_shade.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
             if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
         }
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "srt_device.h"
 
@@ -14,6 +15,8 @@ struct DevScene {
     const DevNode* nodes;
     const DevWide* wide;          // inner nodes with both children's boxes (node-queue kernels), pre-order over inner nodes
     const int32_t* obj_root_info; // n_objects: what an object's ROOT is -- ~(its DevWide index) < 0, or a leaf's (first << 5 | count)
+    const DevNode* root_nodes;    // n_objects: a copy of every object's root record, contiguous -- the root tests of a tile read them with
+                                  // INDEPENDENT loads (index = object) instead of obj_range[ob] -> nodes[root], one dependent pair per object
     const DevTri* tris;
     const DevTriO* tris_o;        // the same triangles as rays from the origin test them (closest-hit phase)
     const int32_t* tri_obj;
@@ -32,7 +35,7 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_objects;
     uint32_t pad_;                // explicit: argument tables are compared bytewise (frame_table), so no implicit padding anywhere
 };
-static_assert(sizeof(DevScene) == 18 * 8 + 16, "DevScene has no implicit padding");
+static_assert(sizeof(DevScene) == 19 * 8 + 16, "DevScene has no implicit padding");
 
 struct DevParams {
     uint32_t W, H, rows;          // W = width of the rows this call writes (local width); rows of them
@@ -596,7 +599,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
                 const uint32_t pl = k & (P - 1), ob = k >> (TWL + THL);
                 const bool ok = k < P * g && ((livem >> pl) & 1ull) && ((root_pass[pl] >> (obj0 + ob)) & 1u);
                 int32_t root = 0, info = -1;
-                if (ok) { root = s.obj_range[obj0 + ob].x; info = s.nodes[root].leaf; }
+                if (ok) { root = s.obj_range[obj0 + ob].x; info = s.root_nodes[obj0 + ob].leaf; }      // two independent loads
                 const bool inner = ok && info < 0, leafp = ok && info >= 0 && (info & LEAF_MAX) != 0;
                 const unsigned long long im = __ballot(inner);
                 if (inner) {
@@ -777,17 +780,52 @@ __device__ __forceinline__ bool background_test_wave(const DevScene& s, const De
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     bool any = false;
     uint32_t pmask = 0;
-    for (uint32_t ob = 0; ob < s.n_objects; ob++) {
-        const int32_t root = s.obj_range[ob].x;                      // wave-uniform: scalar loads
-        const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
-        bool pass;
-        if (FILTER) {
-            bool amb;
-            pass = ray_aabb_filtered(o, rc, a.x, a.y, a.z, a.w, b.x, b.y, amb);
-            if (amb) pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-        } else pass = ray_aabb_nb(o, dd, a.x, a.y, a.z, a.w, b.x, b.y);
-        any |= pass;
-        if (pass && ob < 32u) pmask |= 1u << ob;
+    // four objects at a time: their root records come from the contiguous table by wave-uniform (scalar) loads that depend on nothing
+    // but the object's number, so all eight requests of a group are in flight together (a scene of seven objects used to be a chain of
+    // fourteen dependent round trips before the workgroup's other three waves could start)
+    const float4* rn4 = reinterpret_cast<const float4*>(s.root_nodes);
+    const uint32_t n_obj = s.n_objects;
+    if (p.exp & 2u) {        // A/B: the round-2 loop (obj_range[ob] -> nodes[root], one object after the other)
+        for (uint32_t ob = 0; ob < n_obj; ob++) {
+            const int32_t root = s.obj_range[ob].x;
+            const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+            const bool pass = slab_pass<FILTER>(o, dd, rc, a.x, a.y, a.z, a.w, b.x, b.y);
+            any |= pass;
+            if (pass && ob < 32u) pmask |= 1u << ob;
+        }
+    } else {
+        // G objects at a time (2 for scenes of one or two objects, else 4)
+        auto group = [&](const uint32_t ob0, auto G_) {
+            constexpr uint32_t G = decltype(G_)::value;
+            float4 a[G], b[G];
+#pragma unroll
+            for (uint32_t k = 0; k < G; k++) {
+                const uint32_t ob = ob0 + k < n_obj ? ob0 + k : n_obj - 1u;
+                a[k] = rn4[2 * (size_t)ob]; b[k] = rn4[2 * (size_t)ob + 1];
+            }
+            // (a slot beyond the last object repeats the last object: same bit.)  The filtered tests are one straight line of code, so
+            // the loads above stay together at its head; what the filter could not decide is settled afterwards by the exact form
+            bool pass[G], amb[G];
+            bool any_amb = false;
+#pragma unroll
+            for (uint32_t k = 0; k < G; k++) {
+                if (FILTER) pass[k] = ray_aabb_filtered(o, rc, a[k].x, a[k].y, a[k].z, a[k].w, b[k].x, b[k].y, amb[k]);
+                else { pass[k] = ray_aabb_nb(o, dd, a[k].x, a[k].y, a[k].z, a[k].w, b[k].x, b[k].y); amb[k] = false; }
+                any_amb |= amb[k];
+            }
+            if (FILTER && any_amb) {
+#pragma unroll
+                for (uint32_t k = 0; k < G; k++) if (amb[k]) pass[k] = ray_aabb_nb(o, dd, a[k].x, a[k].y, a[k].z, a[k].w, b[k].x, b[k].y);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < G; k++) {
+                const uint32_t ob = ob0 + k < n_obj ? ob0 + k : n_obj - 1u;
+                any |= pass[k];
+                if (pass[k] && ob < 32u) pmask |= 1u << ob;
+            }
+        };
+        if (n_obj <= 2u) group(0u, std::integral_constant<uint32_t, 2>());
+        else for (uint32_t ob0 = 0; ob0 < n_obj; ob0 += 4u) group(ob0, std::integral_constant<uint32_t, 4>());
     }
     if (root_pass) root_pass[lane] = live ? pmask : 0u;
     const unsigned long long m = __ballot(live && any);
@@ -1051,8 +1089,8 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
             for (uint32_t c = slot; c < n_combo; c += 4u) {
                 const uint32_t lq = c / s.n_objects, ob = c - lq * s.n_objects, l = l_begin + lq;
                 const int32_t root = s.obj_range[ob].x;
+                const float4 a = reinterpret_cast<const float4*>(s.root_nodes)[2 * (size_t)ob], b = reinterpret_cast<const float4*>(s.root_nodes)[2 * (size_t)ob + 1];      // (independent of `root`)
                 if (root == sroot) continue;                          // never the hit object's own tree (:331)
-                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
                 const V3 sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
                 bool pass;
                 if (FILTER) {
@@ -1173,7 +1211,8 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                             const int32_t root = s.obj_range[obj0 + ob].x;
                             ok = root != selfr[rs].x && !flag[rs];                 // never the hit object's own tree (:331)
                             if (ok) {
-                                const float4 a = nodes4[2 * (size_t)root], b = nodes4[2 * (size_t)root + 1];
+                                const float4* rn = reinterpret_cast<const float4*>(s.root_nodes) + 2 * (size_t)(obj0 + ob);
+                                const float4 a = rn[0], b = rn[1];
                                 const float4 o4 = ray[rs], d4 = ray[RS + rs];
                                 const V3 ro = mk(o4.x, o4.y, o4.z), rd = mk(d4.x, d4.y, d4.z);
                                 ok = slab_pass<FILTER>(ro, rd, ray_rcp(rd), a.x, a.y, a.z, a.w, b.x, b.y);
@@ -1372,7 +1411,7 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
 }
 
 // One hit pixel: `shadowed(l)` says whether light sample l's shadow ray was blocked.
-template <typename SH>
+template <bool INT_SHIN = false, typename SH>
 __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevParams& p, const int32_t id, const float t, const uint32_t px, const uint32_t r,
                                                 SH shadowed, float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8) {
     const size_t pix = (size_t)r * p.W + px;
@@ -1411,7 +1450,7 @@ __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevPara
     for (uint32_t l = 0; l < p.n_lights; l++) {                                                 // :366-383
         const V3 L = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]);
         const bool sd = shadowed(l);
-        V3 c = phong(nrm_use, o, d, L, color, ka, ks, sh, t);
+        V3 c = phong<INT_SHIN>(nrm_use, o, d, L, color, ka, ks, sh, t);
         if (sd) c = mk(c.x / p.shadow_div, c.y / p.shadow_div, c.z / p.shadow_div);             // :369
         sum = sum + c;                                                                          // :370
     }
@@ -1565,6 +1604,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameItem* _
 // phongIllumination:144-200, quantiser :447-449, black -> background (:518, drawImage:476-487).
 // Pure ALU, no traversal; misses were finished by the closest-hit kernel.
 // =================================================================================================
+template <bool INT_SHIN = false>
 __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevParams& p, const int32_t* __restrict__ hit_id,
                                                 const float* __restrict__ t_in,
                                                 const unsigned long long* __restrict__ shadow_bits,
@@ -1591,7 +1631,7 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
     const uint32_t sbit = ((((lane >> 5) & 1u) * 2u + ((lane >> 2) & 1u)) << 4) + ((lane >> 3) & 3u) * 4u + (lane & 3u);
     unsigned long long word = 0ull;                        // pixel-major: the pixel's shadow bits of the current 64 samples, loaded once per 64
     const bool px_major = p.shadow_px_major != 0u;
-    shade_hit_pixel(s, p, id, t, px, r, [&](uint32_t l) -> bool {
+    shade_hit_pixel<INT_SHIN>(s, p, id, t, px, r, [&](uint32_t l) -> bool {
         if (px_major) {
             if ((l & 63u) == 0u) word = sb[l >> 6];
             return (word >> (l & 63u)) & 1ull;
@@ -1600,16 +1640,20 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
     }, rgb_linear, rgb8);
 }
 
-__global__ __launch_bounds__(256) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
+// INT_SHIN: every object of the scene has an integer shininess in [1, 64] (the reference's default is 15): the per-sample pow is the
+// square-and-multiply form alone, and the kernel is built for eight waves per SIMD (the general pow's f64 temporaries cost 100 VGPRs)
+template <int INT_SHIN>      // (an int: rocprofv3 consumers take "<true" in a kernel's name for a counting build)
+__global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile(DevScene s, DevParams p, const int32_t* __restrict__ hit_id,
                                                     const float* __restrict__ t_in,
                                                     const unsigned long long* __restrict__ shadow_bits,
                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                                     unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
-    shade_tile_body(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount);
+    shade_tile_body<INT_SHIN != 0>(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount);
 }
-__global__ __launch_bounds__(256) void k_shade_tile_batch(const FrameItem* __restrict__ items) {      // the shading of the frames k_trace_nq_batch traced
+template <int INT_SHIN>
+__global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile_batch(const FrameItem* __restrict__ items) {      // the shading of the frames k_trace_nq_batch traced
     const FrameItem it = items[blockIdx.z];
-    shade_tile_body(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+    shade_tile_body<INT_SHIN != 0>(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
 }
 
 // =================================================================================================

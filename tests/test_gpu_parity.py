@@ -854,6 +854,17 @@ def test_device_pow_against_library_and_host(srt):
     assert (bits(fast[sub]) != bits(host)).mean() < 3e-3 and np.abs(fast[sub] - host).max() < 1e-6
 
 
+@pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("texquad", 120, 90, 3), ("k4", 320, 180, 64), ("main_nocats", 300, 200, 5)])
+def test_integer_shininess_kernel_equals_general(srt, name, W, H, L):
+    """Scenes whose objects all have an integer shininess in [1, 64] are shaded by the kernel built without the general pow (x^e by
+    square-and-multiply alone): bit for bit the general kernel's colours (variant 44 forces the general one)."""
+    g, ds = device_scene(srt, name)
+    a = ds.render(g.params(W, H, L))
+    b = ds.render(g.params(W, H, L, flags=44 << 8))
+    assert np.array_equal(bits(a["rgb_linear"]), bits(b["rgb_linear"])) and np.array_equal(a["rgb8"], b["rgb8"])
+    assert np.array_equal(a["hit_id"], b["hit_id"])
+
+
 def test_valu_issue_rate_is_the_guides(srt):
     """The yardstick of bench.py's roofline, measured: independent v_fma_f32 streams at 8 waves per SIMD issue one wave64 instruction per
     2 cycles per SIMD (MI355X_MICROARCH.md: SIMD-32) -- 0.5 wave-instructions per SIMD-cycle, i.e. 1024 x 32 lane-operations per cycle
