@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 2
+#define SRT_ABI_VERSION 3
 
 /* ---- error codes (the reference signals nothing: it prints, throws or crashes) -- */
 enum {
@@ -185,6 +185,40 @@ int srt_scene_share(srt_scene* src, srt_scene** out);
  * the descriptor's arrays are only read during the call. */
 int srt_scene_update(srt_scene* s, const srt_scene_desc* desc, void* stream);
 
+/* ---- f1, the device half of the per-frame rebuild (Object.cpp:183-190 transform, :205-221 boxes, :225-284 build) ----
+ * The reference re-transforms every triangle and rebuilds every hierarchy per frame.  What the HOST must keep doing for an exact
+ * result is the build's std::sort (its order of equal keys is libstdc++'s; tests/test_host_mirror.py) and, on the way, the node boxes
+ * that choose each split axis.  Everything else of a frame's scene is derived ON THE DEVICE from what that build leaves behind:
+ *   the transformed points in SOURCE order (as the host holds them: object by object, inside an object in load order),
+ *   the permutation the build leaves (visit order -> source index inside the object), and the node boxes in DFS pre-order.
+ * The device gathers the triangles into visit order, derives the ray-independent triangle records (P1 = p1 / w, e1, e2, the face
+ * normal, tvec and qvec of rays from the origin -- the same IEEE operations srt_scene_create runs on the host, bit for bit), permutes
+ * the per-triangle attributes, and writes the boxes into the node records.  Per frame the host sends 52 bytes a triangle and 24 a node
+ * instead of flattening, deriving and copying ~130 bytes a triangle.
+ * Contract: the scene was created (srt_scene_create) from hierarchies of the same SHAPE -- same objects in the same order, same
+ * triangle count per object (the reference's builder halves while a node holds more than 8 triangles, so the shape depends on the
+ * count alone) -- and only positions, order and boxes change.  Counts are checked (SRT_ERR_LAYOUT), the shape cannot be.          */
+typedef struct srt_frame_geometry {
+    uint32_t n_objects;
+    const uint32_t*        obj_n_tris;     /* n_objects: triangles per object (checked against the scene)                      */
+    const uint32_t*        obj_n_nodes;    /* n_objects: nodes per object (checked against the scene)                          */
+    const float* const*    obj_points;     /* per object: n_tris x 3 x 4 transformed points (Triangle::pointOne/Two/Three), SOURCE order */
+    const uint32_t* const* obj_order;      /* per object: n_tris; visit-order triangle i of the object is its source triangle obj_order[k][i] */
+    const float* const*    obj_node_min;   /* per object: n_nodes x 3, the object's nodes in DFS pre-order (root first, left subtree, right subtree) */
+    const float* const*    obj_node_max;
+    const float*           obj_color;      /* n_objects x 3 or NULL (unchanged)                                                */
+    const float*           obj_material;   /* n_objects x 3 or NULL (unchanged)                                                */
+} srt_frame_geometry;
+
+/* Per-triangle attributes in SOURCE order (objects concatenated in the scene's order), set once: srt_scene_update_frame permutes
+ * them into each frame's visit order.  tri_texcoord: n_tris x 6 (needed if the scene has textured triangles), tri_normals: n_tris x 9
+ * or NULL (needed if the scene was created with normals), tri_tex: n_tris texture ids or NULL (= none textured).                   */
+int srt_scene_set_source(srt_scene* s, const float* tri_texcoord, const float* tri_normals, const int32_t* tri_tex);
+
+/* The next frame's geometry, derived on the device (see above).  Asynchronous on `stream` (NULL = the scene's own stream), ordered
+ * behind the renders already enqueued there; the arrays are only read during the call. */
+int srt_scene_update_frame(srt_scene* s, const srt_frame_geometry* g, void* stream);
+
 /* Render into DEVICE buffers (rows = srt_rows_owned(p)); any output pointer may be NULL.
  *   d_hit_id     rows x W   int32   canonical triangle id, -1 = miss
  *   d_t          rows x W   f32     closest-hit distance (+inf on miss)
@@ -258,6 +292,13 @@ int srt_kat_tonemap(int device, uint32_t n, const float* lin, float reinhard, fl
  * roofline prices the kernels' VALU work against).  out[0] = wave-instructions one SIMD issues per cycle (MI355X: SIMD-32, a wave64
  * instruction over 2 cycles -> 0.5), out[1] = shader clock in GHz during the run, out[2] = the same rate over the whole launch span. */
 int srt_debug_valu_rate(int device, uint32_t iters, double* out4);      /* out[3] = waves that shared a SIMD (median) */
+
+/* Test hook: the device records of a scene copied back (any pointer may be NULL): nodes n_nodes x 32 B, tris / tris_o n_tris x 48 B, wide
+ * (n_nodes - n_objects) / 2 x 64 B, root_nodes n_objects x 32 B, tri_texcoord n_tris x 6 floats, tri_normals n_tris x 9 floats, tri_tex
+ * n_tris ids (the last three only where the scene has them).  Waits for the scene's pending work first.  What srt_scene_update_frame
+ * derives on the device is compared, byte for byte, with what srt_scene_create derives on the host. */
+int srt_debug_scene_records(srt_scene* s, void* nodes, void* tris, void* tris_o, void* wide, void* root_nodes,
+                            float* tri_texcoord, float* tri_normals, int32_t* tri_tex);
 
 /* Test hook: the next n host allocations made on behalf of a caller fail (std::bad_alloc inside the library), so that
  * the SRT_ERR_OOM path can be exercised without exhausting memory.  Not for production use. */

@@ -35,6 +35,16 @@ class SceneDesc(C.Structure):
     ]
 
 
+class FrameGeometry(C.Structure):
+    """srt_frame_geometry (include/srt.h, f1 device half): per-object pointer tables."""
+    _fields_ = [
+        ("n_objects", C.c_uint32),
+        ("obj_n_tris", _u32p), ("obj_n_nodes", _u32p),
+        ("obj_points", C.POINTER(_f32p)), ("obj_order", C.POINTER(_u32p)), ("obj_node_min", C.POINTER(_f32p)), ("obj_node_max", C.POINTER(_f32p)),
+        ("obj_color", _f32p), ("obj_material", _f32p),
+    ]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32),

@@ -887,17 +887,21 @@ void ObjectManager::createBoundingHierarchy(const std::string& objFilename) {
     h.order.resize(n);
     Builder b{ h, {}, {}, {}, {}, {} };
     b.p1.resize(3 * (size_t)n); b.lo.resize(3 * (size_t)n); b.hi.resize(3 * (size_t)n); b.scratch.resize(n);
-    for (uint32_t i = 0; i < n; i++) {
-        h.order[i] = i;
-        const Triangle& t = triangles[i];
-        const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
-        for (int c = 0; c < 3; c++) {
-            b.p1[3 * i + c] = t.pointOne[c];
-            float lo = (*p[0])[c], hi = (*p[0])[c];
-            for (int j = 1; j < 3; j++) { const float v = (*p[j])[c]; if (v < lo) lo = v; if (hi < v) hi = v; }
-            b.lo[3 * i + c] = lo; b.hi[3 * i + c] = hi;
+    h.points.resize(12 * (size_t)n);
+    parallel_for(n, 8192, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            h.order[i] = (uint32_t)i;
+            const Triangle& t = triangles[i];
+            const vec4* p[3] = { &t.pointOne, &t.pointTwo, &t.pointThree };
+            for (int j = 0; j < 3; j++) for (int c = 0; c < 4; c++) h.points[12 * i + 4 * j + c] = (*p[j])[c];
+            for (int c = 0; c < 3; c++) {
+                b.p1[3 * i + c] = t.pointOne[c];
+                float lo = (*p[0])[c], hi = (*p[0])[c];
+                for (int j = 1; j < 3; j++) { const float v = (*p[j])[c]; if (v < lo) lo = v; if (hi < v) hi = v; }
+                b.lo[3 * i + c] = lo; b.hi[3 * i + c] = hi;
+            }
         }
-    }
+    });
     const uint32_t nl = n / 2;
     h.nodes.resize(1 + (size_t)Builder::subtree(nl) + Builder::subtree(n - nl));   // the root is always split (:282)
     Node& root = h.nodes[0]; root.first = 0; root.count = n;
@@ -908,6 +912,8 @@ void ObjectManager::createBoundingHierarchy(const std::string& objFilename) {
         if (!BuildPool::get().run_one()) std::this_thread::yield();
     h.triangles.resize(n);                                                       // the nodes' by-value triangles (Object.h:49)
     parallel_for(n, 4096, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) h.triangles[k] = triangles[h.order[k]]; });
+    h.node_min.resize(3 * h.nodes.size()); h.node_max.resize(3 * h.nodes.size());
+    for (size_t i = 0; i < h.nodes.size(); i++) for (int c = 0; c < 3; c++) { h.node_min[3 * i + c] = h.nodes[i].minBox[c]; h.node_max[3 * i + c] = h.nodes[i].maxBox[c]; }
     boundingVolumeHierarchy[objFilename] = std::move(h);
 }
 
@@ -1051,8 +1057,70 @@ Renderer::~Renderer() {
     if (rgb8_) srt_host_free(rgb8_);
 }
 
-// the ObjectManager's current state into the device scene: in place when the counts allow it, else a new scene
+// A sample of the per-triangle attributes the device keeps in source order (texture, texel coordinates, normals): every 61st triangle
+// of every hierarchy, and the identity of the texture images.  Catches another mesh or another material under the same name and counts;
+// an edit of single triangles between two frames of otherwise the same scene is NOT seen -- setFastPath(false) for such callers.
+static uint64_t attribute_sample(ObjectManager* om) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 0x100000001b3ull; } };
+    for (const auto& pair : om->objTriangles) {
+        auto hit = om->boundingVolumeHierarchy.find(pair.first);
+        if (hit == om->boundingVolumeHierarchy.end()) continue;
+        const std::vector<Triangle>& tr = hit->second.triangles;
+        for (size_t i = 0; i < tr.size(); i += 61) {
+            const Triangle& t = tr[i];
+            mix(&t.normalOne, 3 * sizeof(vec3)); mix(&t.colorOneCoordinate, 3 * sizeof(vec2)); mix(t.textureName.data(), t.textureName.size());
+        }
+    }
+    for (const auto& tx : om->textureData) {
+        mix(tx.first.data(), tx.first.size()); mix(&tx.second.dim, sizeof(tx.second.dim));
+        const std::vector<unsigned char>& px = tx.second.rgb;
+        const size_t n = px.size();
+        mix(&n, sizeof(n));
+        for (size_t i = 0; i < n; i += 4099) mix(&px[i], 1);
+    }
+    return h;
+}
+
+// The short way (include/srt.h, f1 device half): the hierarchies' compact arrays straight to srt_scene_update_frame.  false = the
+// resident scene is not this ObjectManager's (first frame, other objects or counts, other attributes): the caller takes the long way.
+bool Renderer::upload_frame(ObjectManager* om) {
+    if (!scene_ || !fast_path_ || sig_names_.size() != om->objTriangles.size()) return false;
+    const size_t nO = sig_names_.size();
+    std::vector<uint32_t> n_tris(nO), n_nodes(nO);
+    std::vector<const float*> pts(nO), bmin(nO), bmax(nO);
+    std::vector<const uint32_t*> ord(nO);
+    std::vector<float> color(3 * nO), mat(3 * nO);
+    size_t k = 0;
+    for (const auto& pair : om->objTriangles) {                 // the iteration order rayIntersection:409 uses (and flattenScene)
+        if (pair.first != sig_names_[k]) return false;
+        auto hit = om->boundingVolumeHierarchy.find(pair.first);
+        if (hit == om->boundingVolumeHierarchy.end()) return false;      // (the long way reports it)
+        const ObjectManager::Hierarchy& h = hit->second;
+        if (h.order.size() != sig_tris_[k] || h.nodes.size() != sig_nodes_[k] || h.points.size() != 12 * h.order.size()) return false;
+        n_tris[k] = sig_tris_[k]; n_nodes[k] = sig_nodes_[k];
+        pts[k] = h.points.data(); ord[k] = h.order.data(); bmin[k] = h.node_min.data(); bmax[k] = h.node_max.data();
+        const vec3 c = om->objColors[pair.first], m = om->objProperties[pair.first];
+        for (int a = 0; a < 3; a++) { color[3 * k + a] = c[a]; mat[3 * k + a] = m[a]; }
+        k++;
+    }
+    if (attribute_sample(om) != sig_attr_) return false;
+    srt_frame_geometry g;
+    std::memset(&g, 0, sizeof(g));
+    g.n_objects = (uint32_t)nO; g.obj_n_tris = n_tris.data(); g.obj_n_nodes = n_nodes.data();
+    g.obj_points = pts.data(); g.obj_order = ord.data(); g.obj_node_min = bmin.data(); g.obj_node_max = bmax.data();
+    g.obj_color = color.data(); g.obj_material = mat.data();
+    const int rc = srt_scene_update_frame(scene_, &g, nullptr);
+    if (rc == SRT_ERR_LAYOUT) return false;
+    if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_update_frame: ") + srt_strerror(rc));
+    fast_frames_++;
+    return true;
+}
+
+// the ObjectManager's current state into the device scene: the device half of the rebuild when the resident scene is this one with
+// other positions (upload_frame), else flattened -- in place when the counts allow it, else a new scene
 void Renderer::upload(ObjectManager* objManager) {
+    if (upload_frame(objManager)) return;
     FlatScene flat = flattenScene(objManager);
     srt_scene_desc d = flat.desc();
     int rc = scene_ ? srt_scene_update(scene_, &d, nullptr) : SRT_ERR_LAYOUT;
@@ -1061,6 +1129,29 @@ void Renderer::upload(ObjectManager* objManager) {
         rc = srt_scene_create(device_, &d, &scene_);
         if (rc != SRT_OK) { scene_ = nullptr; throw std::runtime_error(std::string("srt_scene_create: ") + srt_strerror(rc)); }
     } else if (rc != SRT_OK) throw std::runtime_error(std::string("srt_scene_update: ") + srt_strerror(rc));
+    // what is resident now, and its per-triangle attributes in SOURCE order for the frames that follow (the hierarchies' by-value
+    // copies are in visit order: position i holds source triangle order[i])
+    sig_names_ = flat.names; sig_tris_.clear(); sig_nodes_.clear();
+    const size_t nt = flat.tri_obj.size();
+    std::vector<float> tc(6 * nt), nrm(9 * nt);
+    std::vector<int32_t> tex(nt, -1);
+    bool any_tex = false;
+    size_t base = 0;
+    for (const std::string& name : flat.names) {
+        const ObjectManager::Hierarchy& h = objManager->boundingVolumeHierarchy.at(name);
+        sig_tris_.push_back((uint32_t)h.order.size()); sig_nodes_.push_back((uint32_t)h.nodes.size());
+        for (size_t i = 0; i < h.order.size(); i++) {
+            const size_t src = base + h.order[i], vis = base + i;
+            for (int c = 0; c < 6; c++) tc[6 * src + c] = flat.tri_texcoord[6 * vis + c];
+            for (int c = 0; c < 9; c++) nrm[9 * src + c] = flat.tri_normals[9 * vis + c];
+            tex[src] = flat.tri_tex[vis];
+            any_tex = any_tex || tex[src] >= 0;
+        }
+        base += h.order.size();
+    }
+    sig_attr_ = attribute_sample(objManager);
+    rc = srt_scene_set_source(scene_, tc.data(), nrm.data(), any_tex ? tex.data() : nullptr);
+    if (rc != SRT_OK) { sig_names_.clear(); }              // no short way for this scene (it stays correct: the long way every frame)
 }
 
 void Renderer::enqueue(const vec2& imageSize, const vec4& lightPos, int lightAmount, const mat4* viewMatrix) {

@@ -101,7 +101,12 @@ public:
     // BUILD TIME; triangles = those triangles, copied in that order.  The reference's Node keeps its triangles by value
     // (Object.h:46-57), so what is rendered is the geometry as it was when createBoundingHierarchy ran, whatever
     // transformTriangles / setTriangles do to the object afterwards; the copy keeps that behaviour.
-    struct Hierarchy { std::vector<Node> nodes; std::vector<uint32_t> order; std::vector<Triangle> triangles; };
+    // points / node_min / node_max: what srt_scene_update_frame takes (include/srt.h, f1): the object's transformed points AT BUILD TIME
+    // in source order (12 floats a triangle) and the node boxes in the nodes' (pre-)order (3 floats each).
+    struct Hierarchy {
+        std::vector<Node> nodes; std::vector<uint32_t> order; std::vector<Triangle> triangles;
+        std::vector<float> points, node_min, node_max;
+    };
     std::unordered_map<std::string, vec3> minBox, maxBox;
     std::unordered_map<std::string, vec3> objProperties;       // ambientStrength, specularStrength, shininess
     std::unordered_map<std::string, std::vector<Triangle>> objTriangles;
@@ -167,11 +172,20 @@ public:
     ImageData collect();
     ImageData renderFromCamera(const vec2& imageSize, const vec4& lightPosWorld, const mat4& viewMatrix, ObjectManager* objManager,
                                int lightAmount = 1, bool sceneChanged = false);
+    // upload() takes the device half of the per-frame rebuild (srt_scene_update_frame: 52 bytes a triangle, records derived on the
+    // device) whenever the ObjectManager has the objects (names, order, triangle and node counts), textures and a sample of the
+    // per-triangle attributes of the scene that is resident; anything else goes through flattenScene + srt_scene_update / create.
+    // fastFrames() = how many uploads took the short way (tests, frame_pipeline).
+    uint64_t fastFrames() const { return fast_frames_; }
+    void setFastPath(bool on) { fast_path_ = on; }
 private:
     void upload(ObjectManager* objManager);
+    bool upload_frame(ObjectManager* objManager);
     void enqueue(const vec2& imageSize, const vec4& lightPos, int lightAmount, const mat4* viewMatrix);
     int device_;
     srt_scene* scene_ = nullptr;
+    std::vector<std::string> sig_names_; std::vector<uint32_t> sig_tris_, sig_nodes_; uint64_t sig_attr_ = 0;      // what is resident
+    bool fast_path_ = true; uint64_t fast_frames_ = 0;
     uint8_t* rgb8_ = nullptr; size_t rgb8_bytes_ = 0;      // pinned
     uint32_t W_ = 0, H_ = 0;
     bool pending_ = false;

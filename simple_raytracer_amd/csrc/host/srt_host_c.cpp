@@ -108,6 +108,23 @@ int srth_om_get_points(void* om, const char* name, float* out) {
         }
     })
 }
+// the hierarchy of an object as srt_scene_update_frame takes it: node count, then points (n x 12, source order, at build time), the
+// build's permutation (n), node boxes (m x 3 each, pre-order)
+int64_t srth_om_hierarchy_nodes(void* om, const char* name) {
+    try { return (int64_t)((ObjectManager*)om)->boundingVolumeHierarchy.at(name).nodes.size(); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int srth_om_hierarchy(void* om, const char* name, float* points, uint32_t* order, float* node_min, float* node_max) {
+    GUARD({
+        const ObjectManager::Hierarchy& h = ((ObjectManager*)om)->boundingVolumeHierarchy.at(name);
+        std::memcpy(points, h.points.data(), h.points.size() * sizeof(float));
+        std::memcpy(order, h.order.data(), h.order.size() * sizeof(uint32_t));
+        std::memcpy(node_min, h.node_min.data(), h.node_min.size() * sizeof(float));
+        std::memcpy(node_max, h.node_max.data(), h.node_max.size() * sizeof(float));
+    })
+}
+uint64_t srth_renderer_fast_frames(void* r) { return ((Renderer*)r)->fastFrames(); }
+void srth_renderer_set_fast_path(void* r, int on) { ((Renderer*)r)->setFastPath(on != 0); }
+
 int srth_om_get_tri_attrs(void* om, const char* name, float* texcoord, float* color, int32_t* has_tex, float* normals) {
     GUARD({
         const std::vector<Triangle>& v = ((ObjectManager*)om)->getTriangles(name);

@@ -16,6 +16,7 @@
 #include <memory>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/srt.h"
@@ -64,6 +65,11 @@ struct SceneRecords {
     double overlap = 0.;             // expected slab tests per ray (surface-area estimate, see scene_create_impl)
     bool prefer_packet = false;      // hierarchy of heavily overlapping boxes: primary rays take the packet walk too
     bool int_shin = false;           // every object's shininess is an integer in [1, 64]: the shading kernel without the general pow
+    // host copies of the static topology (srt_scene_update_frame checks counts against them and re-estimates the overlap from a frame's boxes)
+    std::vector<int2> h_ranges; std::vector<int32_t> h_tri_first, h_leaf;
+    // f1, device half: node -> DevWide index (static), this frame's inputs, the per-triangle attributes in source order
+    int32_t* d_widx = nullptr; float4* d_src_points = nullptr; uint32_t* d_order = nullptr; float* d_box_min = nullptr; float* d_box_max = nullptr;
+    float* d_src_tc = nullptr; float* d_src_nrm = nullptr; int32_t* d_src_tex = nullptr; bool have_source = false;
     ~SceneRecords() { (void)hipSetDevice(device); for (void* d : allocs) (void)hipFree(d); }
 };
 
@@ -109,35 +115,6 @@ static int upload(srt_scene* s, const T* host, size_t n, const T** out) {
     s->bytes += bytes;
     *out = (const T*)d;
     return SRT_OK;
-}
-
-// Ray-independent prefix of rayTriangleIntersection:45-51 and calculateTriangleNormal:32-37,
-// evaluated on the host with the same IEEE ops (this TU is built with -ffp-contract=off).
-static DevTri derive_triangle(const float* p) {
-    DevTri t;
-    const float P1x = p[0] / p[3], P1y = p[1] / p[3], P1z = p[2] / p[3];
-    const float P2x = p[4] / p[7], P2y = p[5] / p[7], P2z = p[6] / p[7];
-    const float P3x = p[8] / p[11], P3y = p[9] / p[11], P3z = p[10] / p[11];
-    t.p1x = P1x; t.p1y = P1y; t.p1z = P1z;
-    t.e1x = P2x - P1x; t.e1y = P2y - P1y; t.e1z = P2z - P1z;
-    t.e2x = P3x - P1x; t.e2y = P3y - P1y; t.e2z = P3z - P1z;
-    const float ax = p[4] - p[0], ay = p[5] - p[1], az = p[6] - p[2];       // raw xyz, no w-divide (:33-34)
-    const float bx = p[8] - p[0], by = p[9] - p[1], bz = p[10] - p[2];
-    const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
-    const float s = 1.0f / std::sqrt((cx * cx + cy * cy) + cz * cz);
-    t.nx = cx * s; t.ny = cy * s; t.nz = cz * s;
-    return t;
-}
-
-// tvec = o - P1 with o = 0 (:53) and qvec = cross(tvec, e1) (:58, glm::cross) for rays from the origin
-static DevTriO derive_triangle_origin(const DevTri& t) {
-    DevTriO r;
-    r.tx = 0.0f - t.p1x; r.ty = 0.0f - t.p1y; r.tz = 0.0f - t.p1z;
-    r.e1x = t.e1x; r.e1y = t.e1y; r.e1z = t.e1z; r.e2x = t.e2x; r.e2y = t.e2y; r.e2z = t.e2z;
-    r.qx = r.ty * t.e1z - t.e1y * r.tz;
-    r.qy = r.tz * t.e1x - t.e1z * r.tx;
-    r.qz = r.tx * t.e1y - t.e1x * r.ty;
-    return r;
 }
 
 extern "C" {
@@ -462,7 +439,8 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     const double overlap = overlap_estimate(nodes.data(), d->n_nodes, ranges.data(), d->n_objects);
     const uint32_t n_wide = wide_count(d->n_nodes, d->n_objects);
     std::vector<DevWide> wide(n_wide); std::vector<int32_t> root_info(d->n_objects);
-    { std::vector<int32_t> widx(d->n_nodes); build_wide_records(nodes.data(), d->n_nodes, ranges.data(), d->n_objects, wide.data(), root_info.data(), widx.data()); }
+    std::vector<int32_t> widx(d->n_nodes);
+    build_wide_records(nodes.data(), d->n_nodes, ranges.data(), d->n_objects, wide.data(), root_info.data(), widx.data());
     std::vector<DevTri> tris(d->n_tris);
     std::vector<DevTriO> tris_o(d->n_tris);
     derive_triangles(d, tris.data(), tris_o.data());
@@ -523,6 +501,16 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
     s->rec->overlap = overlap;
     s->rec->prefer_packet = overlap > PACKET_OVERLAP_THRESHOLD;
     s->rec->int_shin = all_integer_shininess(d);
+    {   // what srt_scene_update_frame needs of the topology
+        SceneRecords& r = *s->rec;
+        r.h_ranges = ranges;
+        r.h_tri_first.resize(d->n_objects + 1); derive_tri_first(d, r.h_tri_first.data());
+        r.h_leaf.resize(d->n_nodes); for (uint32_t i = 0; i < d->n_nodes; i++) r.h_leaf[i] = nodes[i].leaf;
+        const int32_t* dw = nullptr;
+        rc = upload(s, widx.data(), widx.size(), &dw);
+        if (rc != SRT_OK) { srt_scene_destroy(s); return rc; }
+        r.d_widx = const_cast<int32_t*>(dw);
+    }
     const hipError_t e = init_handle_state(s);
     if (e != hipSuccess) { g_last_hip = (int)e; srt_scene_destroy(s); return SRT_ERR_DEVICE; }
     *out = s;
@@ -635,7 +623,129 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     s->rec->overlap = overlap_estimate(nodes, d->n_nodes, ranges, d->n_objects);
     s->rec->prefer_packet = s->rec->overlap > PACKET_OVERLAP_THRESHOLD;
     s->rec->int_shin = all_integer_shininess(d);
+    {   // the topology may differ from the previous contents' (same counts, other trees): refresh what srt_scene_update_frame relies on
+        SceneRecords& r = *s->rec;
+        for (uint32_t k = 0; k < d->n_objects; k++) r.h_ranges[k] = ranges[k];
+        derive_tri_first(d, r.h_tri_first.data());
+        for (uint32_t i = 0; i < d->n_nodes; i++) r.h_leaf[i] = nodes[i].leaf;
+        HIP_TRY(hipMemcpyAsync(r.d_widx, h + o_widx, nN * 4, hipMemcpyHostToDevice, stream));
+        r.have_source = false;                                  // attributes in source order belong to the previous contents
+    }
     return SRT_OK;
+}
+
+// ---- f1, device half -------------------------------------------------------------------------------------------------------------
+static int scene_set_source_impl(srt_scene* s, const float* tri_texcoord, const float* tri_normals, const int32_t* tri_tex) {
+    if (!s) return SRT_ERR_ARG;
+    SceneRecords& r = *s->rec;
+    const size_t nT = s->dev.n_tris;
+    if (s->has_tex && (!tri_texcoord || !tri_tex)) return SRT_ERR_ARG;
+    if (s->dev.tri_normals && !tri_normals) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(wait_idle(s));
+    auto put = [&](auto** dst, const auto* src, size_t n) -> int {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
+        if (!*dst) { void* d = nullptr; HIP_TRY(hipMalloc(&d, sizeof(T) * (n ? n : 1))); r.allocs.push_back(d); *dst = (T*)d; s->bytes += sizeof(T) * n; }
+        if (n) HIP_TRY(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+        return SRT_OK;
+    };
+    int rc = SRT_OK;
+    if (s->has_tex) { rc = put(&r.d_src_tc, tri_texcoord, nT * 6); if (rc == SRT_OK) rc = put(&r.d_src_tex, tri_tex, nT); }
+    if (rc == SRT_OK && s->dev.tri_normals) rc = put(&r.d_src_nrm, tri_normals, nT * 9);
+    if (rc != SRT_OK) return rc;
+    r.have_source = true;
+    return SRT_OK;
+}
+
+int srt_scene_set_source(srt_scene* s, const float* tri_texcoord, const float* tri_normals, const int32_t* tri_tex) {
+    return guarded([&] { return scene_set_source_impl(s, tri_texcoord, tri_normals, tri_tex); });
+}
+
+static int scene_update_frame_impl(srt_scene* s, const srt_frame_geometry* g, hipStream_t stream) {
+    if (!s || !g || !g->obj_n_tris || !g->obj_n_nodes || !g->obj_points || !g->obj_order || !g->obj_node_min || !g->obj_node_max) return SRT_ERR_ARG;
+    SceneRecords& r = *s->rec;
+    const uint32_t nO = s->dev.n_objects;
+    if (g->n_objects != nO) return SRT_ERR_LAYOUT;
+    for (uint32_t k = 0; k < nO; k++) {
+        if ((int32_t)g->obj_n_tris[k] != r.h_tri_first[k + 1] - r.h_tri_first[k] || (int32_t)g->obj_n_nodes[k] != r.h_ranges[k].y - r.h_ranges[k].x) return SRT_ERR_LAYOUT;
+        if (g->obj_n_tris[k] && (!g->obj_points[k] || !g->obj_order[k])) return SRT_ERR_ARG;
+        if (!g->obj_node_min[k] || !g->obj_node_max[k]) return SRT_ERR_ARG;
+    }
+    if ((s->has_tex || s->dev.tri_normals) && !r.have_source) return SRT_ERR_ARG;       // attributes cannot be permuted without their source order
+    int rc;
+    if (!stream) { rc = own_stream(s, &stream); if (rc != SRT_OK) return rc; }
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nN = s->dev.n_nodes, nT = s->dev.n_tris;
+    if (!r.d_src_points) {        // the device side of the staging, once
+        auto make = [&](auto** dst, size_t bytes) -> int { void* d = nullptr; HIP_TRY(hipMalloc(&d, bytes ? bytes : 1)); r.allocs.push_back(d); *dst = (std::remove_pointer_t<decltype(dst)>)d; s->bytes += bytes; return SRT_OK; };
+        rc = make(&r.d_src_points, nT * 48); if (rc == SRT_OK) rc = make(&r.d_order, nT * 4);
+        if (rc == SRT_OK) rc = make(&r.d_box_min, nN * 12); if (rc == SRT_OK) rc = make(&r.d_box_max, nN * 12);
+        if (rc != SRT_OK) return rc;
+    }
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_pts = 0, o_ord = o_pts + pad(nT * 48), o_bmin = o_ord + pad(nT * 4), o_bmax = o_bmin + pad(nN * 12), o_col = o_bmax + pad(nN * 12),
+                 o_mat = o_col + pad(nO * 12), total = o_mat + pad(nO * 12);
+    if (s->stage_bytes < total) {
+        if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&s->stage, total, hipHostMallocDefault));
+        s->stage_bytes = total;
+        if (!s->staged) HIP_TRY(hipEventCreateWithFlags(&s->staged, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipEventSynchronize(s->staged));               // the previous update's copies have left the staging block
+    }
+    char* h = (char*)s->stage;
+    for (uint32_t k = 0; k < nO; k++) {
+        const size_t t0 = (size_t)r.h_tri_first[k], nt = g->obj_n_tris[k], n0 = (size_t)r.h_ranges[k].x, nn = g->obj_n_nodes[k];
+        if (nt) { std::memcpy(h + o_pts + t0 * 48, g->obj_points[k], nt * 48); std::memcpy(h + o_ord + t0 * 4, g->obj_order[k], nt * 4); }
+        std::memcpy(h + o_bmin + n0 * 12, g->obj_node_min[k], nn * 12); std::memcpy(h + o_bmax + n0 * 12, g->obj_node_max[k], nn * 12);
+        const uint32_t* ord = g->obj_order[k];
+        for (size_t i = 0; i < nt; i += 4099) if (ord[i] >= nt) return SRT_ERR_LAYOUT;       // (spot check: an index outside the object would read another object's points)
+    }
+    #define CP(dst, off, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync((void*)(dst), h + (off), (bytes), hipMemcpyHostToDevice, stream)); } while (0)
+    CP(r.d_src_points, o_pts, nT * 48); CP(r.d_order, o_ord, nT * 4); CP(r.d_box_min, o_bmin, nN * 12); CP(r.d_box_max, o_bmax, nN * 12);
+    if (g->obj_color) { std::memcpy(h + o_col, g->obj_color, nO * 12); CP(s->dev.obj_color, o_col, nO * 12); }
+    if (g->obj_material) {
+        std::memcpy(h + o_mat, g->obj_material, nO * 12); CP(s->dev.obj_mat, o_mat, nO * 12);
+        bool ish = true;
+        for (uint32_t k = 0; k < nO; k++) { const float sh = g->obj_material[3 * (size_t)k + 2]; ish = ish && sh >= 1.0f && sh <= 64.0f && sh == std::trunc(sh); }
+        r.int_shin = ish;
+    }
+    #undef CP
+    HIP_TRY(hipEventRecord(s->staged, stream));
+    const dim3 block(256);
+    if (nT) hipLaunchKernelGGL(k_update_tris, dim3((uint32_t)((nT + 255) / 256)), block, 0, stream, (uint32_t)nT, s->dev.tri_obj, s->dev.obj_tri_first,
+                               (const float4*)r.d_src_points, (const uint32_t*)r.d_order, const_cast<DevTri*>(s->dev.tris), const_cast<DevTriO*>(s->dev.tris_o),
+                               (const float*)r.d_src_tc, const_cast<float*>(s->dev.tri_tc), (const float*)r.d_src_nrm, const_cast<float*>(s->dev.tri_normals),
+                               (const int32_t*)r.d_src_tex, s->has_tex ? const_cast<int32_t*>(s->dev.tri_tex) : nullptr);
+    hipLaunchKernelGGL(k_update_nodes, dim3((uint32_t)((nN + 255) / 256)), block, 0, stream, (uint32_t)nN, (const float*)r.d_box_min, (const float*)r.d_box_max,
+                       const_cast<DevNode*>(s->dev.nodes), const_cast<DevWide*>(s->dev.wide), (const int32_t*)r.d_widx);
+    hipLaunchKernelGGL(k_update_roots, dim3((nO + 63) / 64), dim3(64), 0, stream, nO, s->dev.obj_range, (const float*)r.d_box_min, (const float*)r.d_box_max,
+                       s->dev.nodes, const_cast<DevNode*>(s->dev.root_nodes));
+    HIP_TRY(hipGetLastError());
+    // expected slab tests per ray from this frame's boxes (what overlap_estimate computes from the records)
+    {
+        const float* bmin = (const float*)(h + o_bmin); const float* bmax = (const float*)(h + o_bmax);
+        auto area = [](const float* a, const float* b) -> double {
+            const double x = (double)b[0] - a[0], y = (double)b[1] - a[1], z = (double)b[2] - a[2];
+            return (x < 0 || y < 0 || z < 0) ? 0. : x * y + y * z + z * x;
+        };
+        float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (uint32_t k = 0; k < nO; k++) {
+            const float* mn = bmin + 3 * (size_t)r.h_ranges[k].x; const float* mx = bmax + 3 * (size_t)r.h_ranges[k].x;
+            if (area(mn, mx) <= 0.) continue;
+            for (int a = 0; a < 3; a++) { lo[a] = mn[a] < lo[a] ? mn[a] : lo[a]; hi[a] = mx[a] > hi[a] ? mx[a] : hi[a]; }
+        }
+        const double tot = area(lo, hi);
+        double sum = 0.;
+        if (tot > 0.) for (size_t i = 0; i < nN; i++) if (r.h_leaf[i] < 0) sum += 2. * area(bmin + 3 * i, bmax + 3 * i);
+        r.overlap = tot > 0. ? (double)nO + sum / tot : 0.;
+        r.prefer_packet = r.overlap > PACKET_OVERLAP_THRESHOLD;
+    }
+    return SRT_OK;
+}
+
+int srt_scene_update_frame(srt_scene* s, const srt_frame_geometry* g, void* stream) {
+    return guarded([&] { return scene_update_frame_impl(s, g, (hipStream_t)stream); });
 }
 
 int srt_scene_update(srt_scene* s, const srt_scene_desc* d, void* stream) {
@@ -643,6 +753,21 @@ int srt_scene_update(srt_scene* s, const srt_scene_desc* d, void* stream) {
 }
 
 void srt_debug_fail_host_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
+
+int srt_debug_scene_records(srt_scene* s, void* nodes, void* tris, void* tris_o, void* wide, void* root_nodes,
+                            float* tri_texcoord, float* tri_normals, int32_t* tri_tex) {
+    if (!s) return SRT_ERR_ARG;
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->stream) HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t nN = s->dev.n_nodes, nT = s->dev.n_tris, nO = s->dev.n_objects, nW = (nN - nO) / 2;
+    #define DOWN(dst, src, bytes) do { if ((dst) && (src) && (bytes)) HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
+    DOWN(nodes, s->dev.nodes, nN * sizeof(DevNode)); DOWN(tris, s->dev.tris, nT * sizeof(DevTri)); DOWN(tris_o, s->dev.tris_o, nT * sizeof(DevTriO));
+    DOWN(wide, s->dev.wide, nW * sizeof(DevWide)); DOWN(root_nodes, s->dev.root_nodes, nO * sizeof(DevNode));
+    DOWN(tri_texcoord, s->dev.tri_tc, nT * 24); DOWN(tri_normals, s->dev.tri_normals, nT * 36); DOWN(tri_tex, s->dev.tri_tex, nT * 4);
+    #undef DOWN
+    return SRT_OK;
+}
 
 uint64_t srt_scene_device_bytes(const srt_scene* s) { return s ? s->bytes : 0; }
 const char* srt_scene_pipeline(const srt_scene* s) { return s ? s->pipeline : ""; }

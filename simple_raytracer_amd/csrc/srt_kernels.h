@@ -1680,6 +1680,88 @@ __global__ __launch_bounds__(256) void k_resolve(DevParams p, const float* __res
 }
 
 // =================================================================================================
+// f1, the device half of the per-frame rebuild (srt_scene_update_frame): the records of a frame from the transformed points in
+// source order, the build's permutation and the node boxes.
+// =================================================================================================
+// Ray-independent prefix of rayTriangleIntersection:45-51 and calculateTriangleNormal:32-37 -- ONE definition for the host
+// (srt_scene_create) and the device (srt_scene_update_frame); both are compiled with -ffp-contract=off and correctly rounded divide /
+// sqrt, so the records are the same bits either way.
+__host__ __device__ inline DevTri derive_triangle(const float* p) {
+    DevTri t;
+    const float P1x = p[0] / p[3], P1y = p[1] / p[3], P1z = p[2] / p[3];
+    const float P2x = p[4] / p[7], P2y = p[5] / p[7], P2z = p[6] / p[7];
+    const float P3x = p[8] / p[11], P3y = p[9] / p[11], P3z = p[10] / p[11];
+    t.p1x = P1x; t.p1y = P1y; t.p1z = P1z;
+    t.e1x = P2x - P1x; t.e1y = P2y - P1y; t.e1z = P2z - P1z;
+    t.e2x = P3x - P1x; t.e2y = P3y - P1y; t.e2z = P3z - P1z;
+    const float ax = p[4] - p[0], ay = p[5] - p[1], az = p[6] - p[2];       // raw xyz, no w-divide (:33-34)
+    const float bx = p[8] - p[0], by = p[9] - p[1], bz = p[10] - p[2];
+    const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+    const float s = 1.0f / sqrtf((cx * cx + cy * cy) + cz * cz);
+    t.nx = cx * s; t.ny = cy * s; t.nz = cz * s;
+    return t;
+}
+// tvec = o - P1 with o = 0 (:53) and qvec = cross(tvec, e1) (:58, glm::cross) for rays from the origin
+__host__ __device__ inline DevTriO derive_triangle_origin(const DevTri& t) {
+    DevTriO r;
+    r.tx = 0.0f - t.p1x; r.ty = 0.0f - t.p1y; r.tz = 0.0f - t.p1z;
+    r.e1x = t.e1x; r.e1y = t.e1y; r.e1z = t.e1z; r.e2x = t.e2x; r.e2y = t.e2y; r.e2z = t.e2z;
+    r.qx = r.ty * t.e1z - t.e1y * r.tz;
+    r.qy = r.tz * t.e1x - t.e1z * r.tx;
+    r.qz = r.tx * t.e1y - t.e1x * r.ty;
+    return r;
+}
+
+// visit-order triangle g <- source triangle first[obj] + order[g]: records derived, attributes permuted
+__global__ __launch_bounds__(256) void k_update_tris(uint32_t n_tris, const int32_t* __restrict__ tri_obj, const int32_t* __restrict__ obj_tri_first,
+                                                     const float4* __restrict__ src_points, const uint32_t* __restrict__ order,
+                                                     DevTri* __restrict__ tris, DevTriO* __restrict__ tris_o,
+                                                     const float* __restrict__ src_tc, float* __restrict__ tri_tc,
+                                                     const float* __restrict__ src_nrm, float* __restrict__ tri_nrm,
+                                                     const int32_t* __restrict__ src_tex, int32_t* __restrict__ tri_tex) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_tris) return;
+    const size_t src = (size_t)obj_tri_first[tri_obj[g]] + order[g];
+    const float4 a = src_points[3 * src], b = src_points[3 * src + 1], c = src_points[3 * src + 2];
+    const float p[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+    const DevTri t = derive_triangle(p);
+    tris[g] = t;
+    tris_o[g] = derive_triangle_origin(t);
+    if (tri_tc && src_tc) for (int k = 0; k < 6; k++) tri_tc[(size_t)g * 6 + k] = src_tc[src * 6 + k];
+    if (tri_nrm && src_nrm) for (int k = 0; k < 9; k++) tri_nrm[(size_t)g * 9 + k] = src_nrm[src * 9 + k];
+    if (tri_tex) tri_tex[g] = src_tex ? src_tex[src] : -1;
+}
+// node i: its box into the 32 B record (skip / leaf stay), into its parent's 64 B record (the record of inner node i holds its
+// CHILDREN's boxes: written by the parent's thread from the box array), and the roots into the contiguous root table
+__global__ __launch_bounds__(256) void k_update_nodes(uint32_t n_nodes, const float* __restrict__ box_min, const float* __restrict__ box_max,
+                                                      DevNode* __restrict__ nodes, DevWide* __restrict__ wide, const int32_t* __restrict__ widx) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    DevNode n = nodes[i];
+    n.minx = box_min[3 * (size_t)i]; n.miny = box_min[3 * (size_t)i + 1]; n.minz = box_min[3 * (size_t)i + 2];
+    n.maxx = box_max[3 * (size_t)i]; n.maxy = box_max[3 * (size_t)i + 1]; n.maxz = box_max[3 * (size_t)i + 2];
+    nodes[i] = n;
+    if (n.leaf < 0) {
+        const size_t l = (size_t)i + 1, r = (size_t)(~n.leaf);
+        DevWide& q = wide[widx[i]];
+        q.lminx = box_min[3 * l]; q.lminy = box_min[3 * l + 1]; q.lminz = box_min[3 * l + 2];
+        q.lmaxx = box_max[3 * l]; q.lmaxy = box_max[3 * l + 1]; q.lmaxz = box_max[3 * l + 2];
+        q.rminx = box_min[3 * r]; q.rminy = box_min[3 * r + 1]; q.rminz = box_min[3 * r + 2];
+        q.rmaxx = box_max[3 * r]; q.rmaxy = box_max[3 * r + 1]; q.rmaxz = box_max[3 * r + 2];
+    }
+}
+__global__ void k_update_roots(uint32_t n_objects, const int2* __restrict__ obj_range, const float* __restrict__ box_min, const float* __restrict__ box_max,
+                               const DevNode* __restrict__ nodes, DevNode* __restrict__ root_nodes) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_objects) return;
+    const int32_t r = obj_range[k].x;
+    DevNode n = nodes[r];                  // (skip / leaf: static; the box from the array, whatever k_update_nodes has written so far)
+    n.minx = box_min[3 * (size_t)r]; n.miny = box_min[3 * (size_t)r + 1]; n.minz = box_min[3 * (size_t)r + 2];
+    n.maxx = box_max[3 * (size_t)r]; n.maxy = box_max[3 * (size_t)r + 1]; n.maxz = box_max[3 * (size_t)r + 2];
+    root_nodes[k] = n;
+}
+
+// =================================================================================================
 // The chip's VALU issue rate, measured (srt_debug_valu_rate): every wave runs `iters` x 64 v_fma_f32 over 16 independent accumulators
 // between two pairs of stamps (s_memtime = shader cycles, s_memrealtime = the constant 100 MHz counter all CUs share) and notes the
 // SIMD it ran on.  With several such waves per SIMD the SIMDs issue back to back, so a SIMD's instructions over the cycles between its

@@ -45,6 +45,12 @@ def load():
         L.srth_om_num_tris.restype = C.c_int64
         L.srth_om_get_points.argtypes = [C.c_void_p, C.c_char_p, _f32p]
         L.srth_om_get_tri_attrs.argtypes = [C.c_void_p, C.c_char_p, _f32p, _f32p, _i32p, _f32p]
+        L.srth_om_hierarchy_nodes.argtypes = [C.c_void_p, C.c_char_p]
+        L.srth_om_hierarchy_nodes.restype = C.c_int64
+        L.srth_om_hierarchy.argtypes = [C.c_void_p, C.c_char_p, _f32p, C.POINTER(C.c_uint32), _f32p, _f32p]
+        L.srth_renderer_fast_frames.argtypes = [C.c_void_p]
+        L.srth_renderer_fast_frames.restype = C.c_uint64
+        L.srth_renderer_set_fast_path.argtypes = [C.c_void_p, C.c_int]
         L.srth_flatten.argtypes = [C.c_void_p]
         L.srth_flatten.restype = C.c_void_p
         L.srth_flat_free.argtypes = [C.c_void_p]
@@ -197,6 +203,16 @@ class ObjectManager:
         out = np.empty((self.num_tris(name), 3, 4), np.float32)
         _ok(self.L.srth_om_get_points(self.om, name.encode(), _p(out))); return out
 
+    def hierarchy(self, name):
+        """(points n x 3 x 4 in source order at build time, order n, node_min m x 3, node_max m x 3): what srt_scene_update_frame takes."""
+        n, m = self.num_tris(name), int(self.L.srth_om_hierarchy_nodes(self.om, name.encode()))
+        if m < 0:
+            raise KeyError(name)
+        pts, order = np.empty((n, 3, 4), np.float32), np.empty(n, np.uint32)
+        mn, mx = np.empty((m, 3), np.float32), np.empty((m, 3), np.float32)
+        _ok(self.L.srth_om_hierarchy(self.om, name.encode(), _p(pts), order.ctypes.data_as(C.POINTER(C.c_uint32)), _p(mn), _p(mx)))
+        return pts, order, mn, mx
+
     def tri_attrs(self, name):
         n = self.num_tris(name)
         tc, col, ht, nrm = np.empty((n, 6), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.int32), np.empty((n, 9), np.float32)
@@ -270,6 +286,14 @@ class Renderer:
     def render(self, om, W, H, light4, light_amount=1, image=True):
         light4 = _f(light4); rgb = self._out(W, H, image)
         return self._ret(self.L.srth_renderer_render(self.h, om.om, W, H, _p(light4), light_amount, _p(rgb) if image else None), rgb)
+
+    @property
+    def fast_frames(self):
+        """Uploads that took the device half of the rebuild (srt_scene_update_frame) instead of flatten + srt_scene_update."""
+        return int(self.L.srth_renderer_fast_frames(self.h))
+
+    def set_fast_path(self, on):
+        self.L.srth_renderer_set_fast_path(self.h, int(bool(on)))
 
     def submit(self, om, W, H, light4, light_amount=1):
         light4 = _f(light4)

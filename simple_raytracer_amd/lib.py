@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libsrt_hip.so")
 ABI_SYMBOLS = ("srt_params_default", "srt_light_staircase", "srt_rows_owned", "srt_cols_owned", "srt_scene_create", "srt_scene_destroy", "srt_scene_update", "srt_scene_share",
                "srt_render_device", "srt_render_device_batch", "srt_render", "srt_render_async", "srt_host_alloc", "srt_host_free", "srt_sync", "srt_scene_device_bytes", "srt_strerror",
                "srt_last_hip_error", "srt_abi_version", "srt_kat_ray_aabb", "srt_kat_ray_triangle", "srt_kat_phong", "srt_kat_tonemap", "srt_kat_interp_normal", "srt_kat_pow",
-               "srt_debug_fail_host_allocs", "srt_debug_valu_rate", "srt_scene_pipeline", "srt_scene_overlap_estimate")
+               "srt_debug_fail_host_allocs", "srt_debug_valu_rate", "srt_debug_scene_records", "srt_scene_set_source", "srt_scene_update_frame",
+               "srt_scene_pipeline", "srt_scene_overlap_estimate")
 
 _f32p, _i32p, _u8p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 _lib = None
@@ -124,6 +125,46 @@ class DeviceScene:
         d = flat.desc()
         _check(self.L.srt_scene_update(self.h, C.byref(d), C.c_void_p(stream)), "srt_scene_update")
         self.flat = flat
+
+    def set_source(self, tri_texcoord=None, tri_normals=None, tri_tex=None):
+        """srt_scene_set_source: per-triangle attributes in SOURCE order (objects concatenated), for update_frame."""
+        a = [None if x is None else np.ascontiguousarray(x, ty) for x, ty in ((tri_texcoord, np.float32), (tri_normals, np.float32), (tri_tex, np.int32))]
+        self.L.srt_scene_set_source.argtypes = [C.c_void_p, _f32p, _f32p, _i32p]
+        _check(self.L.srt_scene_set_source(self.h, a[0].ctypes.data_as(_f32p) if a[0] is not None else None, a[1].ctypes.data_as(_f32p) if a[1] is not None else None,
+                                           a[2].ctypes.data_as(_i32p) if a[2] is not None else None), "srt_scene_set_source")
+
+    def update_frame(self, points, order, node_min, node_max, obj_color=None, obj_material=None, stream=0):
+        """srt_scene_update_frame: per object the transformed points in source order (n x 3 x 4), the build's permutation (n), the node
+        boxes in DFS pre-order (m x 3 each); the records are derived on the device."""
+        n = len(points)
+        pts = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in points]
+        ords = [np.ascontiguousarray(x, np.uint32) for x in order]
+        mn = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in node_min]
+        mx = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in node_max]
+        g = abi.FrameGeometry()
+        g.n_objects = n
+        nt = (C.c_uint32 * n)(*[o.shape[0] for o in ords]); nn = (C.c_uint32 * n)(*[m.shape[0] // 3 for m in mn])
+        pp = (_f32p * n)(*[p.ctypes.data_as(_f32p) for p in pts]); po = (C.POINTER(C.c_uint32) * n)(*[o.ctypes.data_as(C.POINTER(C.c_uint32)) for o in ords])
+        pmn = (_f32p * n)(*[m.ctypes.data_as(_f32p) for m in mn]); pmx = (_f32p * n)(*[m.ctypes.data_as(_f32p) for m in mx])
+        g.obj_n_tris, g.obj_n_nodes, g.obj_points, g.obj_order, g.obj_node_min, g.obj_node_max = nt, nn, pp, po, pmn, pmx
+        col = None if obj_color is None else np.ascontiguousarray(obj_color, np.float32)
+        mat = None if obj_material is None else np.ascontiguousarray(obj_material, np.float32)
+        g.obj_color = col.ctypes.data_as(_f32p) if col is not None else None
+        g.obj_material = mat.ctypes.data_as(_f32p) if mat is not None else None
+        self.L.srt_scene_update_frame.argtypes = [C.c_void_p, C.POINTER(abi.FrameGeometry), C.c_void_p]
+        _check(self.L.srt_scene_update_frame(self.h, C.byref(g), C.c_void_p(stream)), "srt_scene_update_frame")
+
+    def records(self):
+        """srt_debug_scene_records: the device records as raw numpy arrays (dict)."""
+        nN, nT, nO = self.flat.n_nodes, self.flat.n_tris, self.flat.n_objects
+        out = {"nodes": np.zeros((nN, 8), np.uint32), "tris": np.zeros((nT, 12), np.uint32), "tris_o": np.zeros((nT, 12), np.uint32),
+               "wide": np.zeros(((nN - nO) // 2, 16), np.uint32), "root_nodes": np.zeros((nO, 8), np.uint32),
+               "tri_texcoord": np.zeros((nT, 6), np.float32), "tri_normals": np.zeros((nT, 9), np.float32), "tri_tex": np.full(nT, -7, np.int32)}
+        self.L.srt_debug_scene_records.argtypes = [C.c_void_p] * 6 + [_f32p, _f32p, _i32p]
+        v = lambda k: out[k].ctypes.data_as(C.c_void_p)
+        _check(self.L.srt_debug_scene_records(self.h, v("nodes"), v("tris"), v("tris_o"), v("wide"), v("root_nodes"), out["tri_texcoord"].ctypes.data_as(_f32p),
+                                              out["tri_normals"].ctypes.data_as(_f32p), out["tri_tex"].ctypes.data_as(_i32p)), "srt_debug_scene_records")
+        return out
 
     def close(self):
         if getattr(self, "h", None):

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(L):
     assert declared == set(lib.ABI_SYMBOLS), declared ^ set(lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.srt_abi_version() == 2
+    assert L.srt_abi_version() == 3
 
 
 def test_struct_sizes_match_header(L):

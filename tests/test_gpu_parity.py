@@ -380,6 +380,113 @@ def test_textured_asset_from_files_through_the_loader_to_hip(srt, oracle, tmp_pa
     check_rgb8(o["rgb8"], c["rgb8"], max_frac=1e-3)
 
 
+def test_device_half_of_the_rebuild_gives_the_hosts_records(srt, oracle):
+    """f1, device half (srt_scene_update_frame): the host sends a frame's transformed points in SOURCE order, the permutation its
+    hierarchy build leaves and the node boxes; the device gathers, derives the triangle records (P1 = p1 / w, e1, e2, face normal, tvec,
+    qvec), permutes the attributes and writes the boxes.  Every device record -- 32 B nodes, 64 B inner nodes, root table, both triangle
+    records, texel coordinates, normals, texture ids -- must be, byte for byte, what srt_scene_create derives on the host from the
+    flattened scene of the same frame; and the frames must be the oracle's.  Bunny + cube orbit, then a textured scene."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    meshes = {k: gu.load_mesh(k) for k in ("cube", "bunny")}
+    def frame(angle):
+        r = scenes.Recipe()
+        r.load("bunny", "bunny"); r.color("bunny", (0.9, 0.9, 0.9))
+        r.transform("bunny", T.scaleObj(1500.0, 1500.0, 1500.0)); r.transform("bunny", T.rotateObjX(T.radians(180.0 + angle)))
+        r.transform("bunny", T.changeObjPosition(20.0, 170.0, 300.0)); r.bvh("bunny")
+        r.load("cube", "cube"); r.color("cube", (0.2, 0.7, 0.3))
+        r.transform("cube", T.scaleObj(400.0, 10.0, 400.0)); r.transform("cube", T.changeObjPosition(0.0, 130.0, 350.0)); r.bvh("cube")
+        om = host.ObjectManager(); r.replay(om, meshes)
+        return om
+    def source_attrs(om, flat, names):
+        """per-triangle attributes in source order, from the flat (visit-order) arrays and the hierarchies' permutations"""
+        tc, nrm, tex = np.zeros_like(flat.tri_texcoord), np.zeros_like(flat.tri_normals), np.full(flat.n_tris, -1, np.int32)
+        base = 0
+        for nme in names:
+            _, order, _, _ = om.hierarchy(nme)
+            src = base + order.astype(np.int64); vis = base + np.arange(order.shape[0])
+            tc.reshape(-1, 6)[src] = flat.tri_texcoord.reshape(-1, 6)[vis]; nrm.reshape(-1, 9)[src] = flat.tri_normals.reshape(-1, 9)[vis]
+            tex[src] = flat.tri_tex[vis]
+            base += order.shape[0]
+        return tc, nrm, tex
+    def check(ds, om, names, p):
+        flat = om.flatten()
+        hs = [om.hierarchy(nme) for nme in names]
+        ds.update_frame([h[0] for h in hs], [h[1] for h in hs], [h[2] for h in hs], [h[3] for h in hs], obj_color=flat.obj_color, obj_material=flat.obj_material)
+        got = ds.records()
+        fresh = srt.DeviceScene(flat)
+        want = fresh.records()
+        for k in ("nodes", "wide", "root_nodes", "tris", "tris_o", "tri_tex"):
+            assert np.array_equal(got[k], want[k]), k
+        for k in ("tri_texcoord", "tri_normals"):
+            assert np.array_equal(bits(got[k]), bits(want[k])), k
+        o = ds.render(p); f = fresh.render(p); c = oracle.render(flat, p)
+        assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+        assert np.array_equal(bits(o["rgb_linear"]), bits(f["rgb_linear"])) and np.array_equal(o["rgb8"], f["rgb8"])
+        assert abs(ds.overlap_estimate - fresh.overlap_estimate) < 1e-6 * fresh.overlap_estimate
+    om0 = frame(0.0)
+    flat0 = om0.flatten()
+    names = flat0.names
+    ds = srt.DeviceScene(flat0)
+    ds.set_source(*source_attrs(om0, flat0, names))
+    p = abi.make_params(192, 108, abi.light_staircase((300.0, -600.0, -100.0), 2))
+    for angle in (7.0, 31.0, 0.0):
+        check(ds, frame(angle), names, p)
+    # counts of another scene: refused, nothing written
+    g, _ = device_scene(srt, "cube")
+    with pytest.raises(srt.SrtError) as e:
+        ds.update_frame([np.zeros((12, 3, 4), np.float32)], [np.arange(12, dtype=np.uint32)], [np.zeros((3, 3), np.float32)], [np.zeros((3, 3), np.float32)])
+    assert e.value.code == abi.SRT_ERR_LAYOUT
+    # a textured scene (a slice of the tree mesh over an untextured slab), two poses: attributes must follow the permutation
+    m = gu.load_mesh("tree")
+    ptsT, tcT, texT = m["points"][:6000], m["texcoord"][:6000], m["texture"]
+    def textured(angle):
+        om = host.ObjectManager()
+        om.add_textured_object("tree", ptsT, tcT, "bark", texT)
+        om.transformTriangles("tree", T.scaleObj(0.1, 0.1, 0.1)); om.transformTriangles("tree", T.rotateObjX(T.radians(-90.0)))
+        om.transformTriangles("tree", T.rotateObjY(T.radians(angle))); om.transformTriangles("tree", T.changeObjPosition(0.0, 20.0, 120.0))
+        om.createBoundingHierarchy("tree")
+        om.add_object("ground", meshes["cube"]); om.setColor("ground", (0.3, 0.6, 0.3))
+        om.transformTriangles("ground", T.scaleObj(60.0, 2.0, 60.0)); om.transformTriangles("ground", T.changeObjPosition(0.0, 23.0, 125.0))
+        om.createBoundingHierarchy("ground")
+        return om
+    omq = textured(0.0)
+    flatq = omq.flatten(); namesq = flatq.names
+    assert flatq.n_textures == 1 and (flatq.tri_tex >= 0).sum() == 6000
+    dq = srt.DeviceScene(flatq)
+    with pytest.raises(srt.SrtError):                      # textured triangles and no source attributes yet
+        hs = [omq.hierarchy(nme) for nme in namesq]
+        dq.update_frame([h[0] for h in hs], [h[1] for h in hs], [h[2] for h in hs], [h[3] for h in hs])
+    dq.set_source(*source_attrs(omq, flatq, namesq))
+    pq = abi.make_params(200, 150, abi.light_staircase((120.0, -260.0, -40.0), 2))
+    for angle in (25.0, 0.0):
+        check(dq, textured(angle), namesq, pq)
+
+
+def test_renderer_takes_the_device_half_from_the_second_frame(srt, oracle):
+    """srt_host::Renderer: the first frame of an orbit is flattened and uploaded, the following ones go through
+    srt_scene_update_frame (fast_frames counts them) -- same pictures as with the short way switched off, and the oracle's."""
+    import scenes
+    from simple_raytracer_amd import host
+    T = host.Transformation
+    cube = gu.load_mesh("cube")
+    W, H = 160, 120
+    fast, slow = host.Renderer(0), host.Renderer(0)
+    slow.set_fast_path(False)
+    for k, angle in enumerate((0.0, 10.0, 20.0, 30.0)):
+        rec = scenes.four_cubes(T, angle)
+        om = host.ObjectManager(); rec.replay(om, {"cube": cube})
+        a, na = fast.render(om, W, H, list(rec.light) + [1.0], light_amount=2)
+        b, nb = slow.render(om, W, H, list(rec.light) + [1.0], light_amount=2)
+        assert na == nb and np.array_equal(a, b), angle
+        p = abi.make_params(W, H, abi.light_staircase(rec.light, 2)); p.background[0] = p.background[1] = p.background[2] = 0
+        want = oracle.render(om.flatten(), p)["rgb8"].astype(np.float32)
+        d = np.abs(a - want)
+        assert d.max() <= 1.0 and (d.max(-1) > 0).sum() <= 2
+    assert fast.fast_frames == 3 and slow.fast_frames == 0
+
+
 def test_scene_update_with_other_texture_images(srt, oracle):
     """A second scene with the SAME counts but other pictures through one device scene (what a renderer that keeps its scene does
     with a caller's next ObjectManager): srt_scene_update compares the texture table and the images' content hash, uploads changed
