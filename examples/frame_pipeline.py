@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--builders", type=lambda v: [int(x) for x in v.split(",")], default=[2, 3, 4], help="frames built concurrently in mode 3b, e.g. 2,3,4")
+    ap.add_argument("--serial-builders", type=lambda v: [int(x) for x in v.split(",")], default=[6, 8, 12], help="frames built concurrently in mode 3c (one thread per build)")
     a = ap.parse_args()
     W, H, N = a.width, a.height, a.frames
     bunny, cube = gu.load_mesh("bunny"), gu.load_mesh("cube")
@@ -144,6 +145,23 @@ def main():
             for x in fut:
                 x.result()
         print(f" 3b. pipelined, {nb} frames being built at any time: {wall2:.3f} ms per frame, exact")
+
+    # ---- 3c. the same with every hierarchy build on its own thread alone (no pool tasks inside a build): more frames in the builders'
+    # hands, each build slower, the cores never waiting for each other
+    host.set_build_tasks(False)
+    for nb in a.serial_builders:
+        with cf.ThreadPoolExecutor(nb) as ex:
+            fut = [ex.submit(build_frame, k, bunny, cube) for k in range(nb)]
+            t0 = time.perf_counter()
+            for f in range(3 * N):
+                om = fut[f % nb].result()
+                fut[f % nb] = ex.submit(build_frame, f + nb, bunny, cube)
+                n = r.render(om, W, H, LIGHT, image=False)
+            wall3 = (time.perf_counter() - t0) * 1e3 / (3 * N)
+            for x in fut:
+                x.result()
+        print(f" 3c. pipelined, {nb} frames being built at any time, each build on one thread: {wall3:.3f} ms per frame, exact")
+    host.set_build_tasks(True)
 
     # ---- 4. camera mode: world-space scene, hierarchies built once, one matrix per frame ---------------------------------------
     om = build_frame(0, bunny, cube)

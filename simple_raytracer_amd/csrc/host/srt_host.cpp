@@ -65,7 +65,7 @@ private:
     void loop() {
         for (;;) {
             bool ran = false;
-            for (int spin = 0; spin < 4000 && !ran; spin++) { ran = run_one(); if (!ran) std::this_thread::yield(); }
+            for (int spin = 0; spin < 400 && !ran; spin++) { ran = run_one(); if (!ran) std::this_thread::yield(); }
             if (ran) continue;
             std::unique_lock<std::mutex> g(m_);
             cv_.wait(g, [this] { return !q_.empty(); });
@@ -75,6 +75,13 @@ private:
     std::atomic<int> queued_{0};
     unsigned n_ = 0;
 };
+
+// One hierarchy build cut into pool tasks (the default: lowest latency for ONE frame), or every build on its caller's thread alone
+// (setHierarchyBuildTasks(false)): a host that builds the hierarchies of SEVERAL frames at once on threads of its own -- the orbit
+// pipeline -- gets more frames per second out of the same cores that way, because a build's tasks spend most of their life waiting
+// for each other (the top-level sorts are serial stretches) and the waiting threads take the cores the other frames' builds need.
+std::atomic<bool> g_build_tasks{true};
+inline bool build_tasks_allowed() { return g_build_tasks.load(std::memory_order_relaxed) && BuildPool::get().workers(); }
 
 // fn(begin, end) over [0, n) in chunks of at least `grain`, on the pool plus the calling thread
 void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
@@ -787,7 +794,7 @@ struct ExactSort {
             KeyIdx* mid = first + (last - first) / 2;
             median_to_first(first, first + 1, mid, last - 1);
             KeyIdx* cut = partition(first + 1, last, first);
-            if (last - cut >= PAR_MIN && BuildPool::get().workers()) {
+            if (last - cut >= PAR_MIN && build_tasks_allowed()) {
                 pending.fetch_add(1, std::memory_order_relaxed);
                 BuildPool::get().submit([this, cut, last, depth_limit] { loop(cut, last, depth_limit); pending.fetch_sub(1, std::memory_order_release); });
             } else loop(cut, last, depth_limit);
@@ -857,7 +864,7 @@ struct Builder {
         L.first = first; L.count = nl; bounds(L.first, L.count, L.minBox, L.maxBox);
         R.first = first + nl; R.count = nr; bounds(R.first, R.count, R.minBox, R.maxBox);
         // the two halves touch disjoint ranges of order / scratch and disjoint node slots
-        if (nl > 8 && nr > 8 && depth < PAR_DEPTH && n >= PAR_MIN && BuildPool::get().workers()) {
+        if (nl > 8 && nr > 8 && depth < PAR_DEPTH && n >= PAR_MIN && build_tasks_allowed()) {
             pending.fetch_add(1, std::memory_order_relaxed);
             BuildPool::get().submit([this, li, depth] { split(li, depth + 1); pending.fetch_sub(1, std::memory_order_release); });
             split(ri, depth + 1);
@@ -870,6 +877,8 @@ struct Builder {
     static constexpr uint32_t PAR_MIN = 2048;    // not worth a task below this
 };
 } // namespace
+
+void setHierarchyBuildTasks(bool on) { g_build_tasks.store(on, std::memory_order_relaxed); }
 
 // test hook: the permutation the builder's parallel sort gives and the one std::sort gives (they must be the same)
 void sort_keys_both_ways(const float* keys, uint32_t n, uint32_t* order_parallel, uint32_t* order_std) {

@@ -89,6 +89,9 @@ struct Node {
 struct Texture { std::vector<unsigned char> rgb; ivec2 dim; };
 // baseline / progressive JPEG -> 8-bit RGB with stb_image's arithmetic (srt_jpeg.cpp)
 bool decode_jpeg(const std::vector<unsigned char>& file_bytes, Texture& out);
+// createBoundingHierarchy as pool tasks (default) or on the calling thread alone (false): for hosts that build several frames'
+// hierarchies concurrently on their own threads (examples/frame_pipeline.py).  Same trees either way.
+void setHierarchyBuildTasks(bool on);
 // test hook for the hierarchy builder's sort (srt_host.cpp, ExactSort): both permutations of 0..n-1 by keys[]
 void sort_keys_both_ways(const float* keys, uint32_t n, uint32_t* order_parallel, uint32_t* order_std);
 // what stbi_load(path, &w, &h, &ch, 3) gives the reference (Object.cpp:57): PNG / JPEG / PPM / BMP by content

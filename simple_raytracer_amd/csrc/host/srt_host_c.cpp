@@ -92,6 +92,7 @@ int srth_om_clone(void* om_, const char* src, const char* dst) {
 int srth_om_set_color(void* om, const char* name, float r, float g, float b) { GUARD(((ObjectManager*)om)->setColor(name, vec3(r, g, b))) }
 int srth_om_set_props(void* om, const char* name, float ka, float ks, float sh) { GUARD(((ObjectManager*)om)->objProperties[name] = vec3(ka, ks, sh)) }
 int srth_om_transform(void* om, const char* name, const float* m) { GUARD(((ObjectManager*)om)->transformTriangles(name, to_mat(m))) }
+void srth_set_build_tasks(int on) { setHierarchyBuildTasks(on != 0); }
 int srth_sort_keys_both_ways(const float* keys, uint32_t n, uint32_t* order_parallel, uint32_t* order_std) {
     GUARD(sort_keys_both_ways(keys, n, order_parallel, order_std))
 }

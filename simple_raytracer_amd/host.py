@@ -94,6 +94,11 @@ def _f(a):
     return np.ascontiguousarray(a, np.float32)
 
 
+def set_build_tasks(on):
+    """createBoundingHierarchy cut into pool tasks (True, default) or on the calling thread alone (False: for several frames built concurrently)."""
+    load().srth_set_build_tasks(int(bool(on)))
+
+
 class HostError(RuntimeError):
     pass
 
