@@ -1108,6 +1108,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         }
     }
     uint32_t nqn = 0, tqn = 0;
+    unsigned long long dg_k = 0, dg_m = 0, dg_steps = 0;      // (diagnostic, variant 47)
 
     // one batch of <= 64 queued (leaf, ray) pairs: the lane walks the leaf's triangles until one hits
     auto tri_batch = [&]() {
@@ -1233,6 +1234,14 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
                         int32_t linfo = 0, rinfo = 0, node = 0, rnode = 0;
                         bool in_l = false, in_r = false, lf_l = false, lf_r = false;
                         V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 1.f);
+                        if (p.exp & 4u) {        // diagnostic (variant 47): how many DISTINCT records does a step read?
+                            const uint32_t e_ = lane < m ? nq[nqn + lane] : 0xffffffffu;
+                            const uint32_t w_ = e_ >> 6, prev_ = (uint32_t)__shfl_up((int)w_, 1, 64);
+                            const bool live_ = lane < m && !flag[e_ & 63u];
+                            dg_k += (unsigned long long)__popcll(__ballot(live_ && (lane == 0 || w_ != prev_)));
+                            dg_m += (unsigned long long)__popcll(__ballot(live_));
+                            dg_steps++;
+                        }
                         if (lane < m) {
                             const uint32_t e = nq[nqn + lane];
                             rs = e & 63u;
@@ -1389,6 +1398,7 @@ __device__ __forceinline__ void shadow_phase(const DevScene& s, const DevParams&
         __builtin_amdgcn_wave_barrier();
     }
     if (SEQ) { wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri); }
+    if (!SEQ && (p.exp & 4u) && lane == 0) { atomicAdd(counters + 5, dg_k); atomicAdd(counters + 6, dg_m); atomicAdd(counters + 7, dg_steps); }
 }
 
 // blockIdx.z = chunk of `l_chunk` light samples: with many samples a tile's shadow rays are cut over several workgroups (a
