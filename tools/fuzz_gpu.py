@@ -88,6 +88,11 @@ def main():
         ok = ok and (not fin.any() or float(np.abs(o["rgb_linear"][fin] - c["rgb_linear"][fin]).max()) < tol)
         d8 = np.abs(o["rgb8"].astype(np.int32) - c["rgb8"].astype(np.int32))
         ok = ok and d8.max() <= 1 and int((d8.max(-1) > 0).sum()) <= max(2, W * H // 2000)
+        # the other forms of the node-queue kernels (64 B records everywhere, 32 B everywhere, the round-2 queue order): the same frame bit for bit
+        if "ray_matrix" not in kw:
+            for variant in (40, 41, 42):
+                ov = ds.render(abi.make_params(W, H, lights, flags=variant << 8, **kw))
+                ok = ok and np.array_equal(ov["hit_id"], o["hit_id"]) and np.array_equal(bits(ov["t"]), bits(o["t"])) and np.array_equal(bits(ov["rgb_linear"]), bits(o["rgb_linear"]))
         # the batch call: this frame and a second one with the light moved, on shared records, against the single renders
         twin = ds.share()
         light2 = np.asarray(recipe.light, np.float32) + np.float32(17.0)
