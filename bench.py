@@ -323,6 +323,7 @@ def measure(args):
     render_frames(p, streams=False)
     torch.cuda.synchronize()
     st = scene.sync()
+    pipeline = scene.pipeline                  # what the library launched for this frame (the counting launch below may take another route)
     rgb8 = gather.tiles[0][0]
 
     # the eager single-stream re-render of the same frame must be bitwise what the timed region (graph replay) wrote
@@ -336,7 +337,6 @@ def measure(args):
     scene.render_device(pc, stream=stream, hit_id=hit[0].data_ptr(), t=tbuf[0].data_ptr(), rgb_linear=lin[0].data_ptr(), rgb8=rgb8.data_ptr())
     torch.cuda.synchronize()
     sc = scene.sync()
-    pipeline = scene.pipeline
     rays_rank = sc["primary_rays"] + sc["shadow_rays"]        # of one of this rank's frames (its scanline blocks)
     # ---- parity of the frame the timed region rendered last (rank 0, whole frames only) -------------------------------
     parity = None

@@ -953,11 +953,17 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         // in camera mode goes through the packet closest-hit kernel, which takes a general ray
         const bool cam_nq = fp.cam && variant == 0 && !count && !s->rec->prefer_packet && p->n_lights >= 1 && p->n_lights < 8 && !fp.xcd_rows && (p->flags >> 8 & 0xffu) != 35;
         const bool pk_closest = (fp.cam && !cam_nq) || variant == 22 || variant == 23 || (variant == 0 && s->rec->prefer_packet && !force_nq);
-        const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8));
+        // 8 .. 15 samples on a scene whose rays test few nodes (expected slab tests per ray < 14: cube scenes 3-6, bunny over a slab 12):
+        // the node-queue shadow kernel with the samples cut over blockIdx.z beats the packet walk since round 3's queue order (K3 with
+        // 8 / 12 samples 0.212 / 0.281 ms against 0.254 / 0.321, cube over ground with 8: 0.107 against 0.197); the composite scene
+        // (seven objects, tree crowns; estimate 17+) and 16+ samples stay with the packet walk (K4 with 8 / 12: 0.390 / 0.473 against 0.416 / 0.621)
+        const bool few_nodes_mid = variant == 0 && !count && !fp.cam && p->n_lights >= 8 && p->n_lights < 16 && s->rec->overlap < 14.0 && !s->rec->prefer_packet &&
+                                   (p->flags >> 8 & 0xffu) == 0;
+        const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8 && !few_nodes_mid));
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
-        const bool chunked = p->n_lights >= 8 && !count && variant == 20;
+        const bool chunked = p->n_lights >= 8 && !count && (variant == 20 || few_nodes_mid);
         const bool fused = (variant == 0 || variant > 10) && p->n_lights && !chunked && !pk_shadow && !pk_closest && variant != 20;     // (variants 11, 17, 18 are configurations of the fused kernel)
         const dim3 grid8x(grid8.x, fp.xcd_rows ? (grid8.y + 7) / 8 * 8 : grid8.y);      // whole tile rows per XCD: y padded to 8 rows
         bool shaded = false;               // the trace launch shaded its tiles itself

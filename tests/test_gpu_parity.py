@@ -166,11 +166,12 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
         g = ga if k % 3 else gb
         light = g.light.copy(); light[0] += 40.0 * k
         frames.append((g, abi.make_params(W, H, abi.light_staircase(light, 1 + k % 3), block_rows=8, block_first=1, block_stride=3)))
-    frames.append((ga, ga.params(W, H, 9)))                                     # packet shadow pipeline at another size: launched on its own
+    frames.append((ga, ga.params(W, H, 17)))                                    # packet shadow pipeline at another size: launched on its own
     frames.append((gb, gb.params(128, 96, 2)))                                  # fused, but another size: second group
     frames.append((ga, abi.make_params(W, H, abi.light_staircase(ga.light, 2), block_rows=8, block_first=1, block_stride=3, flags=abi.SRT_FLAG_COUNT_WORK)))
-    for L in (9, 12, 64):                                                       # 8+ samples at the common size: the second shared group (three launches)
-        frames.append((ga if L != 12 else gb, abi.make_params(W, H, abi.light_staircase(ga.light, L), block_rows=8, block_first=1, block_stride=3)))
+    for L in (16, 20, 64):                                                      # 16+ samples at the common size: the second shared group (three launches)
+        frames.append((ga if L != 20 else gb, abi.make_params(W, H, abi.light_staircase(ga.light, L), block_rows=8, block_first=1, block_stride=3)))
+    frames.append((ga, abi.make_params(W, H, abi.light_staircase(ga.light, 9), block_rows=8, block_first=1, block_stride=3)))      # 8..15 samples on a scene of few nodes per ray: node-queue shadow kernel, samples in chunks; launched on its own
     # frames of the same scene share ONE copy of its device records (srt_scene_share); the handle that uploaded them goes first
     first = {id(ga): srt.DeviceScene(ga.flat), id(gb): srt.DeviceScene(gb.flat)}
     handles = [first[id(g)].share() for g, _ in frames]
@@ -198,6 +199,7 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
             one.close()
     assert handles[0].pipeline == "k_trace_nq+k_shade_tile (batched)" and handles[11].pipeline == "k_closest_hit_nq+k_shadow_pk+k_shade_tile"
     assert handles[14].pipeline == handles[16].pipeline == "k_closest_hit_nq+k_shadow_pk+k_shade_tile (batched)"
+    assert handles[17].pipeline == "k_closest_hit_nq+k_shadow_nq+k_shade_tile"
     # a handle twice in one call: refused before anything is enqueued
     with pytest.raises(srt.SrtError) as e:
         srt.FrameBatch([handles[0], handles[0]], [frames[0][1]] * 2).render()
