@@ -6,6 +6,7 @@
 // 348-401, 321-342, 144-200).  No CPU fallback exists in this library.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -312,6 +313,17 @@ static void build_wide_records(const DevNode* nodes, uint32_t n_nodes, const int
     }
 }
 
+// the union of the objects' root boxes, in a node's box layout (min.xyz max.x | max.yz 0 0): what a tile's rays are tested against
+// before the roots themselves in scenes of several objects (srt_kernels.h background_test_wave)
+static void union_of_roots(const DevNode* roots, uint32_t n, float* out8) {
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (uint32_t k = 0; k < n; k++) {
+        const float mn[3] = { roots[k].minx, roots[k].miny, roots[k].minz }, mx[3] = { roots[k].maxx, roots[k].maxy, roots[k].maxz };
+        for (int a = 0; a < 3; a++) { if (mn[a] < lo[a]) lo[a] = mn[a]; if (mx[a] > hi[a]) hi[a] = mx[a]; }
+    }
+    out8[0] = lo[0]; out8[1] = lo[1]; out8[2] = lo[2]; out8[3] = hi[0]; out8[4] = hi[1]; out8[5] = hi[2]; out8[6] = 0.f; out8[7] = 0.f;
+}
+
 // 64-bit content hash of a byte range (texture images: srt_scene_update re-uploads them only when it changes).  Eight independent
 // multiply-xor lanes over 64-byte blocks: memory-bound on one core.
 static uint64_t content_hash(const uint8_t* p, size_t n) {
@@ -461,6 +473,9 @@ static int scene_create_impl(int device, const srt_scene_desc* d, srt_scene** ou
         std::vector<DevNode> roots(d->n_objects);
         for (uint32_t k = 0; k < d->n_objects; k++) roots[k] = nodes[ranges[k].x];
         UP(upload(s, roots.data(), roots.size(), &s->dev.root_nodes));
+        float ub[8];
+        union_of_roots(roots.data(), d->n_objects, ub);
+        UP(upload(s, ub, 8, &s->dev.scene_box));
     }
     UP(upload(s, tris.data(), tris.size(), &s->dev.tris));
     UP(upload(s, tris_o.data(), tris_o.size(), &s->dev.tris_o));
@@ -579,7 +594,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
                  o_triobj = o_triso + pad(nT * sizeof(DevTriO)), o_ranges = o_triobj + pad(nT * 4), o_first = o_ranges + pad(nO * sizeof(int2)),
                  o_color = o_first + pad((nO + 1) * 4), o_mat = o_color + pad(nO * 12), o_nrm = o_mat + pad(nO * 12),
                  o_tex = o_nrm + pad(d->tri_normals ? nT * 36 : 0), o_tc = o_tex + pad(any_tex ? nT * 4 : 0), o_wide = o_tc + pad(any_tex ? nT * 24 : 0),
-                 o_rinfo = o_wide + pad(nW * sizeof(DevWide)), o_widx = o_rinfo + pad(nO * 4), o_roots = o_widx + pad(nN * 4), o_img = o_roots + pad(nO * sizeof(DevNode)),
+                 o_rinfo = o_wide + pad(nW * sizeof(DevWide)), o_widx = o_rinfo + pad(nO * 4), o_roots = o_widx + pad(nN * 4), o_ubox = o_roots + pad(nO * sizeof(DevNode)), o_img = o_ubox + pad(32),
                  total = o_img + pad(tex_changed ? tex_total : 0);
     if (s->stage_bytes < total) {
         if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
@@ -595,6 +610,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     if (rc != SRT_OK) return rc;
     build_wide_records(nodes, d->n_nodes, ranges, d->n_objects, (DevWide*)(h + o_wide), (int32_t*)(h + o_rinfo), (int32_t*)(h + o_widx));
     for (uint32_t k = 0; k < d->n_objects; k++) ((DevNode*)(h + o_roots))[k] = nodes[ranges[k].x];
+    union_of_roots((const DevNode*)(h + o_roots), d->n_objects, (float*)(h + o_ubox));
     if (tex_changed) std::memcpy(h + o_img, d->tex_rgb, tex_total);
     derive_triangles(d, (DevTri*)(h + o_tris), (DevTriO*)(h + o_triso));
     derive_tri_first(d, (int32_t*)(h + o_first));
@@ -608,6 +624,7 @@ static int scene_update_impl(srt_scene* s, const srt_scene_desc* d, hipStream_t 
     CP(s->dev.wide, o_wide, nW * sizeof(DevWide));
     CP(s->dev.obj_root_info, o_rinfo, nO * 4);
     CP(s->dev.root_nodes, o_roots, nO * sizeof(DevNode));
+    CP(s->dev.scene_box, o_ubox, 32);
     if (tex_changed) { CP(s->dev.tex, o_img, tex_total); s->rec->tex_hash = tex_hash_new; }
     CP(s->dev.tris, o_tris, nT * sizeof(DevTri));
     CP(s->dev.tris_o, o_triso, nT * sizeof(DevTriO));
@@ -684,7 +701,7 @@ static int scene_update_frame_impl(srt_scene* s, const srt_frame_geometry* g, hi
     }
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_pts = 0, o_ord = o_pts + pad(nT * 48), o_bmin = o_ord + pad(nT * 4), o_bmax = o_bmin + pad(nN * 12), o_col = o_bmax + pad(nN * 12),
-                 o_mat = o_col + pad(nO * 12), total = o_mat + pad(nO * 12);
+                 o_mat = o_col + pad(nO * 12), o_ubox = o_mat + pad(nO * 12), total = o_ubox + pad(32);
     if (s->stage_bytes < total) {
         if (s->stage) { HIP_TRY(hipEventSynchronize(s->staged)); (void)hipHostFree(s->stage); s->stage = nullptr; s->stage_bytes = 0; }
         HIP_TRY(hipHostMalloc(&s->stage, total, hipHostMallocDefault));
@@ -702,7 +719,17 @@ static int scene_update_frame_impl(srt_scene* s, const srt_frame_geometry* g, hi
         for (size_t i = 0; i < nt; i += 4099) if (ord[i] >= nt) return SRT_ERR_LAYOUT;       // (spot check: an index outside the object would read another object's points)
     }
     #define CP(dst, off, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync((void*)(dst), h + (off), (bytes), hipMemcpyHostToDevice, stream)); } while (0)
+    {   // the union of this frame's root boxes
+        float* ub = (float*)(h + o_ubox);
+        float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+        for (uint32_t k = 0; k < nO; k++) {
+            const float* mn = (const float*)(h + o_bmin) + 3 * (size_t)r.h_ranges[k].x; const float* mx = (const float*)(h + o_bmax) + 3 * (size_t)r.h_ranges[k].x;
+            for (int a = 0; a < 3; a++) { if (mn[a] < lo[a]) lo[a] = mn[a]; if (mx[a] > hi[a]) hi[a] = mx[a]; }
+        }
+        ub[0] = lo[0]; ub[1] = lo[1]; ub[2] = lo[2]; ub[3] = hi[0]; ub[4] = hi[1]; ub[5] = hi[2]; ub[6] = 0.f; ub[7] = 0.f;
+    }
     CP(r.d_src_points, o_pts, nT * 48); CP(r.d_order, o_ord, nT * 4); CP(r.d_box_min, o_bmin, nN * 12); CP(r.d_box_max, o_bmax, nN * 12);
+    CP(s->dev.scene_box, o_ubox, 32);
     if (g->obj_color) { std::memcpy(h + o_col, g->obj_color, nO * 12); CP(s->dev.obj_color, o_col, nO * 12); }
     if (g->obj_material) {
         std::memcpy(h + o_mat, g->obj_material, nO * 12); CP(s->dev.obj_mat, o_mat, nO * 12);
@@ -880,7 +907,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // node-queue kernel (node-major order); 43: the shipped kernels with pushes in lane order.  Shipped (0): node-major order; 32 B records
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
-    dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
+    dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.pad2_ = 0u;
     if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 47)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;

@@ -17,6 +17,7 @@ struct DevScene {
     const int32_t* obj_root_info; // n_objects: what an object's ROOT is -- ~(its DevWide index) < 0, or a leaf's (first << 5 | count)
     const DevNode* root_nodes;    // n_objects: a copy of every object's root record, contiguous -- the root tests of a tile read them with
                                   // INDEPENDENT loads (index = object) instead of obj_range[ob] -> nodes[root], one dependent pair per object
+    const float* scene_box;       // 8 floats (min.xyz max.x | max.yz - -): the union of the objects' root boxes, laid out like a node's box
     const DevTri* tris;
     const DevTriO* tris_o;        // the same triangles as rays from the origin test them (closest-hit phase)
     const int32_t* tri_obj;
@@ -35,7 +36,7 @@ struct DevScene {
     uint32_t n_nodes, n_tris, n_objects;
     uint32_t pad_;                // explicit: argument tables are compared bytewise (frame_table), so no implicit padding anywhere
 };
-static_assert(sizeof(DevScene) == 19 * 8 + 16, "DevScene has no implicit padding");
+static_assert(sizeof(DevScene) == 20 * 8 + 16, "DevScene has no implicit padding");
 
 struct DevParams {
     uint32_t W, H, rows;          // W = width of the rows this call writes (local width); rows of them
@@ -785,6 +786,20 @@ __device__ __forceinline__ bool background_test_wave(const DevScene& s, const De
     // fourteen dependent round trips before the workgroup's other three waves could start)
     const float4* rn4 = reinterpret_cast<const float4*>(s.root_nodes);
     const uint32_t n_obj = s.n_objects;
+    // Scenes of several objects: the union of their root boxes first.  A ray that CERTAINLY fails it -- filtered test decided, not
+    // ambiguous: tfar_U < tnear_U by more than the margin -- fails every root box inside it under the reference's own comparisons: per
+    // axis an inner box's t-interval nests in the union's, so tnear_A >= tnear_U and tfar_A <= tfar_U, and tnear_A - tfar_A exceeds both
+    // the union's margin (2e-6 of |tnear_U| + |tfar_U|) and, when A's values are much larger than the union's, half of |tnear_A| +
+    // |tfar_A| itself -- either way far more than the half-ulp the correctly rounded quotients of A can move.  Most tiles of a 4K frame
+    // of the reference's scenes are sky: one test instead of one per object on the path every tile waits behind.
+    bool skip_roots = false;
+    if (FILTER && n_obj >= 3u && !(p.exp & 10u)) {      // (variants 45 / 46 switch it off, A/B)
+        const float4 ua = reinterpret_cast<const float4*>(s.scene_box)[0], ub = reinterpret_cast<const float4*>(s.scene_box)[1];
+        bool amb_u;
+        const bool pass_u = ray_aabb_filtered(o, rc, ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, amb_u);
+        skip_roots = !__ballot(live && (pass_u || amb_u));
+    }
+    if (skip_roots) { /* no ray can pass any root: pmask stays 0 */ } else
     if (p.exp & 2u) {        // A/B: the round-2 loop (obj_range[ob] -> nodes[root], one object after the other)
         for (uint32_t ob = 0; ob < n_obj; ob++) {
             const int32_t root = s.obj_range[ob].x;
