@@ -1746,7 +1746,9 @@ __global__ __launch_bounds__(256) void k_update_tris(uint32_t n_tris, const int3
                                                      const int32_t* __restrict__ src_tex, int32_t* __restrict__ tri_tex) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n_tris) return;
-    const size_t src = (size_t)obj_tri_first[tri_obj[g]] + order[g];
+    const int32_t ob = tri_obj[g], f0 = obj_tri_first[ob], cnt = obj_tri_first[ob + 1] - f0;
+    const uint32_t oi = order[g];
+    const size_t src = (size_t)f0 + (oi < (uint32_t)cnt ? oi : (uint32_t)(cnt - 1));      // (an index outside the object -- a caller's error -- must not become an access outside the buffers)
     const float4 a = src_points[3 * src], b = src_points[3 * src + 1], c = src_points[3 * src + 2];
     const float p[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
     const DevTri t = derive_triangle(p);
