@@ -909,7 +909,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.pad2_ = 0u;
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 47)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 54)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -1027,9 +1027,10 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 else if (variant == 11) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (variant == 12) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // round-1 form: roots re-tested per wave (A/B)
                 else if (variant == 17) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 5, 64>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 64 shadow rays in flight per wave
+                else if ((p->flags >> 8 & 0xffu) == 54) hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // (A/B) the build for 6 waves per SIMD (rounds 1-2)
                 else if (all_wide)      hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, false, false, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
                 else if (fp.xcd_rows)   hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16, true>), grid8x, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
-                else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);
+                else                    hipLaunchKernelGGL((k_trace_nq<false, 512, true, 7, 16>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr);      // 72 VGPRs (14 spills), 7 waves per SIMD: since the node-major order 3 % ahead of the 6-wave build (80 VGPRs, 5 spills); round 2's kernel lost 2.5 % that way
             } else if (bc && !count && (p->flags >> 8 & 0xffu) == 0 && pk_shadow && !pk_closest && spp == 1 && bc->accepts(wl, rows)) {
                 // 8+ light samples, held back: node-queue closest hit, packet shadow kernel and shading of the batch's frames in three launches
                 FrameItem it{s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr, zero_next, s->d_qcount, s->ws_qlist, s->qcap, 0u};
@@ -1046,6 +1047,11 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                                    s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
             } else if (all_wide && !count) {
                 hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
+            } else if (!count && (p->flags >> 8 & 0xffu) != 53) {
+                // built for 7 waves per SIMD (72 VGPRs, 5 spills; 76 without the bound: 6 waves): a frame of mostly background tiles is a stream
+                // of short workgroups, and one more resident per SIMD is worth the spills -- K4 closest hit 0.234 -> 0.223 ms, frame 1.285 -> 1.236
+                // (variant 53 = the unbounded build, A/B)
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, false, 7>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, o_lin, o_rgb8, ctr, ql_cnt, ql, s->qcap);
             } else {
                 LAUNCH_NQ(512, 2, 2, true);
             }
@@ -1214,7 +1220,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
             const uint32_t wgs1 = (uint32_t)(max_units / 4 + 1 < wgs_all ? max_units / 4 + 1 : wgs_all);
             for (const FrameItem& it : bc.items_pk) {
-                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true>), dim3(g8.x, g8.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, it.qcount, it.qlist, it.qcap);
+                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, false, 7>), dim3(g8.x, g8.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, it.qcount, it.qlist, it.qcap);
                 hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs1), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
                 hipLaunchKernelGGL(k_shade_tile<0>, dim3(g16.x, g16.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
                 if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
@@ -1228,7 +1234,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
     int rc = frame_table(scenes[0], bc.items, stream, &table);
     const dim3 block(256), g_trace((bc.wl + 7) / 8, (bc.rows + 7) / 8, (uint32_t)held), g_shade((bc.wl + 15) / 16, (bc.rows + 15) / 16, (uint32_t)held);
     if (rc == SRT_OK && table) {
-        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 6, 16>), g_trace, block, 0, stream, table);
+        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 7, 16>), g_trace, block, 0, stream, table);
         if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
         if (rc == SRT_OK) {
             if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g_shade, block, 0, stream, table);
@@ -1237,7 +1243,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         }
     } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
         for (const FrameItem& it : bc.items) {
-            hipLaunchKernelGGL((k_trace_nq<false, 512, true, 6, 16>), dim3(g_trace.x, g_trace.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
+            hipLaunchKernelGGL((k_trace_nq<false, 512, true, 7, 16>), dim3(g_trace.x, g_trace.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
             hipLaunchKernelGGL(k_shade_tile<0>, dim3(g_shade.x, g_shade.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
             if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
         }

@@ -879,8 +879,8 @@ __device__ __forceinline__ bool finish_background_tile(const DevScene& s, const 
 // then work through the live tiles one after the other (four waves per tile, as ever).  For frames that are mostly background
 // (3840x2160 of the reference's scenes: 94 % of 129,600 tiles) the launch is bound by workgroup dispatch, and this is a quarter
 // of the workgroups; the host picks it for big frames only (a frame full of geometry keeps the finer grid's balance).
-template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false, bool WIDE = false>
-__global__ __launch_bounds__(256) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
+template <bool COUNT, int NQCAP, int TWL, int THL, bool FILTER, bool COARSE = false, bool WIDE = false, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_closest_hit_nq(DevScene s, DevParams p, int32_t* __restrict__ hit_id,
                                                         float* __restrict__ t_out, float* __restrict__ rgb_linear,
                                                         uint8_t* __restrict__ rgb8, unsigned long long* __restrict__ counters,
                                                         uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap) {
@@ -1601,7 +1601,7 @@ struct FrameItem {
 static_assert(sizeof(FrameItem) == sizeof(DevScene) + sizeof(DevParams) + 9 * 8 + 8, "FrameItem has no implicit padding");
 // the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)
 template <int NQCAP, bool FILTER>
-__global__ __launch_bounds__(256) void k_closest_hit_nq_batch(const FrameItem* __restrict__ items) {
+__global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameItem* __restrict__ items) {
     const FrameItem it = items[blockIdx.z];
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];

@@ -742,7 +742,7 @@ def test_dropin_entry_point_matches_reference_image(srt):
         assert abs(n - int((np.any(want != np.array(abi.REFERENCE_BACKGROUND, np.uint8), axis=-1)).sum())) <= 2
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 18, 20, 21, 22, 23, 24, 40, 41, 42, 43, 45, 46])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 10, 11, 18, 20, 21, 22, 23, 24, 40, 41, 42, 43, 45, 46, 53, 54])
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 1), ("cubes4_a0", 128, 96, 8), ("spheres6", 160, 120, 1),
                                         ("texquad", 120, 90, 1), ("cube", 37, 23, 1)])
 def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
