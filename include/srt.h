@@ -212,7 +212,8 @@ typedef struct srt_frame_geometry {
 
 /* Per-triangle attributes in SOURCE order (objects concatenated in the scene's order), set once: srt_scene_update_frame permutes
  * them into each frame's visit order.  tri_texcoord: n_tris x 6 (needed if the scene has textured triangles), tri_normals: n_tris x 9
- * or NULL (needed if the scene was created with normals), tri_tex: n_tris texture ids or NULL (= none textured).                   */
+ * or NULL (needed if the scene was created with normals), tri_tex: n_tris texture ids or NULL (= none textured).  A later
+ * srt_scene_update (a whole new flat scene) discards them: set them again before the next srt_scene_update_frame.                 */
 int srt_scene_set_source(srt_scene* s, const float* tri_texcoord, const float* tri_normals, const int32_t* tri_tex);
 
 /* The next frame's geometry, derived on the device (see above).  Asynchronous on `stream` (NULL = the scene's own stream), ordered
