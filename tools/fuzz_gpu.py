@@ -17,7 +17,8 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def random_scene(rng, cube, bunny):
+def random_scene(rng, cube, bunny, pose=None):
+    """pose = (angle, dx): every object turned and moved once more before its hierarchy is built (the next frame of an orbit)"""
     recipe = scenes.Recipe(); meshes = {"cube": cube}
     T = host.Transformation
     n_obj = int(rng.integers(1, 9))
@@ -51,13 +52,50 @@ def random_scene(rng, cube, bunny):
             pts[..., :3] = c + rng.uniform(-1, 1, (n, 3, 3)) * rng.choice([3.0, 25.0, 120.0])
             meshes[f"m{k}"] = pts
             recipe.load(name, f"m{k}")
+        if pose is not None:
+            recipe.transform(name, T.rotateObjY(T.radians(pose[0]))); recipe.transform(name, T.changeObjPosition(pose[1], 0.0, 0.0))
         recipe.color(name, rng.uniform(0, 1, 3)); recipe.bvh(name)
     recipe.light = tuple(float(x) for x in rng.uniform(-500, 500, 3))
     return recipe, meshes
 
 
+def replay(recipe, meshes):
+    om = host.ObjectManager(); recipe.replay(om, meshes)
+    return om
+
+
+def source_attrs(om, flat):
+    tc, nrm, tex = np.zeros_like(flat.tri_texcoord), np.zeros_like(flat.tri_normals), np.full(flat.n_tris, -1, np.int32)
+    base = 0
+    for nme in flat.names:
+        order = om.hierarchy(nme)[1]
+        src = base + order.astype(np.int64); vis = base + np.arange(order.shape[0])
+        tc.reshape(-1, 6)[src] = flat.tri_texcoord.reshape(-1, 6)[vis]; nrm.reshape(-1, 9)[src] = flat.tri_normals.reshape(-1, 9)[vis]
+        tex[src] = flat.tri_tex[vis]
+        base += order.shape[0]
+    return tc, nrm, tex
+
+
+def update_frame_leg(seed, cube, bunny, ds, flat, p):
+    rng0 = np.random.default_rng(1000 + seed)
+    recipe0, meshes0 = random_scene(rng0, cube, bunny)
+    ds.set_source(*source_attrs(replay(recipe0, meshes0), flat))
+    rng1 = np.random.default_rng(1000 + seed)
+    recipe1, meshes1 = random_scene(rng1, cube, bunny, pose=(float(seed % 90) + 3.5, float(seed % 7) - 3.0))
+    om1 = replay(recipe1, meshes1)
+    flat1 = om1.flatten()
+    hs = [om1.hierarchy(nme) for nme in flat1.names]
+    ds.update_frame([h[0] for h in hs], [h[1] for h in hs], [h[2] for h in hs], [h[3] for h in hs], obj_color=flat1.obj_color, obj_material=flat1.obj_material)
+    fresh = lib.DeviceScene(flat1)
+    got, want = ds.records(), fresh.records()
+    ok = all(np.array_equal(np.ascontiguousarray(got[k]).view(np.uint8), np.ascontiguousarray(want[k]).view(np.uint8)) for k in ("nodes", "wide", "root_nodes", "tris", "tris_o", "tri_tex", "tri_texcoord", "tri_normals"))
+    o, f = ds.render(p), fresh.render(p)
+    return ok and np.array_equal(o["hit_id"], f["hit_id"]) and np.array_equal(bits(o["t"]), bits(f["t"])) and np.array_equal(bits(o["rgb_linear"]), bits(f["rgb_linear"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--update-frames", action="store_true", help="also check srt_scene_update_frame against srt_scene_create on a second pose of every scene")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--first", type=int, default=0)
     a = ap.parse_args()
@@ -107,6 +145,10 @@ def main():
         ok = ok and np.array_equal(views[0], o["hit_id"]) and np.array_equal(views[1], o2["hit_id"])
         for x in hp:
             lib.load().srt_host_free(x)
+        # the device half of the rebuild: the same objects in another pose through srt_scene_update_frame -- every record what a
+        # fresh srt_scene_create derives on the host, and the frame the fresh scene's
+        if a.update_frames:
+            ok = ok and update_frame_leg(seed, cube, bunny, ds, flat, p)
         print(f"seed {seed:3d}: {len(flat.names)} objects, {flat.tri_points.shape[0]:5d} triangles, {W}x{H}, L={L:2d}, {({k: v for k, v in kw.items() if k != 'ray_matrix'} or 'whole')}{' camera' if 'ray_matrix' in kw else ''}: "
               f"{ds.pipeline:45s} hits {int((c['hit_id'] >= 0).sum()):6d}  {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += 0 if ok else 1
