@@ -87,9 +87,6 @@ struct srt_scene {
     unsigned long long* d_ctr_last = nullptr;     // set written by the most recent render
     uint64_t render_seq = 0;
     bool ctr_dirty = false;                       // a render returned an error after its first launch
-    struct FrameTable { std::vector<FrameItem> host; FrameItem* dev = nullptr; size_t n = 0; uint64_t stamp = 0; bool pinned = false; };      // pinned: handed out to a capturing stream (a graph may replay it for ever)
-    std::vector<FrameTable> tables;               // argument tables of the batches this handle led (srt_render_device_batch)
-    uint64_t table_clock = 0;
     char pipeline[96] = "";                       // kernels of the last render, in launch order
     uint32_t n_textures = 0; bool has_tex = false;
     void* stage = nullptr; size_t stage_bytes = 0; hipEvent_t staged = nullptr;      // pinned staging of srt_scene_update
@@ -207,7 +204,6 @@ int srt_scene_destroy(srt_scene* s) {
     (void)hipSetDevice(s->device);
     (void)wait_idle(s);
     s->rec.reset();                      // frees the records with their last handle
-    for (auto& e : s->tables) (void)hipFree(e.dev);
     if (s->ws_hit) (void)hipFree(s->ws_hit);
     if (s->ws_t) (void)hipFree(s->ws_t);
     if (s->ws_lin) (void)hipFree(s->ws_lin);
@@ -909,7 +905,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.pad2_ = 0u;
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 54)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 58)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -1066,6 +1062,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * 8 ? max_units / 4 + 1 : (uint64_t)s->n_cu * 8);
             if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
+            else if ((p->flags >> 8 & 0xffu) == 55)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // record of i + 1 requested ahead (A/B)
+            else if ((p->flags >> 8 & 0xffu) == 56)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 2>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // + skip[i] / first triangle (A/B)
+            else if ((p->flags >> 8 & 0xffu) == 57)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 0>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // the plain walk (A/B)
             else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // records through LDS windows (A/B)
             else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
@@ -1140,44 +1139,6 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream, int32_t* 
     return guarded([&] { return render_device_impl(s, p, stream, d_hit_id, d_t, d_rgb_linear, d_rgb8); });
 }
 
-// The argument table of a batch in device memory.  A step re-issues the same batch (same handles, parameters and outputs; the two
-// counter sets of a handle alternate, so two tables), and a captured hipGraph replays it: tables are immutable once made and kept on
-// the first handle of the batch, found again by content.  A new table is allocated and copied with blocking calls, which a capturing
-// stream does not allow: *out stays null then and the caller launches the frames one by one (issue the batch once before capturing).
-constexpr size_t FRAME_TABLES_KEPT = 128;      // (a table is 352 bytes a frame)
-static int frame_table(srt_scene* owner, const std::vector<FrameItem>& items, hipStream_t stream, const FrameItem** out) {
-    const size_t bytes = items.size() * sizeof(FrameItem);
-    *out = nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    HIP_TRY(hipStreamIsCapturing(stream, &cap));
-    for (auto& e : owner->tables) {
-        if (e.n != items.size() || std::memcmp(e.host.data(), items.data(), bytes) != 0) continue;      // (the records have no implicit padding: static_asserts in srt_kernels.h)
-        e.stamp = ++owner->table_clock;
-        if (cap != hipStreamCaptureStatusNone) e.pinned = true;      // a captured graph keeps reading this table: never evicted
-        *out = e.dev;
-        return SRT_OK;
-    }
-    if (cap != hipStreamCaptureStatusNone) return SRT_OK;
-    if (owner->tables.size() >= FRAME_TABLES_KEPT) {            // forget the table used longest ago that no graph can hold (hipFree waits for the device)
-        size_t old = owner->tables.size();
-        for (size_t k = 0; k < owner->tables.size(); k++)
-            if (!owner->tables[k].pinned && (old == owner->tables.size() || owner->tables[k].stamp < owner->tables[old].stamp)) old = k;
-        if (old == owner->tables.size()) return SRT_ERR_LIMIT;  // every remembered batch belongs to a captured graph
-        (void)hipFree(owner->tables[old].dev);
-        owner->tables.erase(owner->tables.begin() + old);
-    }
-    alloc_gate();
-    srt_scene::FrameTable e;
-    e.host = items;
-    e.n = items.size(); e.stamp = ++owner->table_clock;
-    if (hipMalloc((void**)&e.dev, bytes) != hipSuccess) { (void)hipGetLastError(); return SRT_ERR_OOM; }
-    const hipError_t err = hipMemcpy(e.dev, e.host.data(), bytes, hipMemcpyHostToDevice);
-    if (err != hipSuccess) { (void)hipFree(e.dev); g_last_hip = (int)err; return SRT_ERR_DEVICE; }
-    owner->tables.push_back(std::move(e));
-    *out = owner->tables.back().dev;
-    return SRT_OK;
-}
-
 // The frames of a step in as few launches as their arguments fit (srt.h).  Every frame goes through render_device_impl -- the same
 // checks, workspaces, light upload and counter sets as a single render; frames that take the fused pipeline at one size are held back
 // and launched together, the others (another pipeline, counting build, supersampling, a different size) are launched as they come.
@@ -1202,51 +1163,35 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
                                           d_rgb_linear ? d_rgb_linear[i] : nullptr, d_rgb8 ? d_rgb8[i] : nullptr, &bc);
         if (rc != SRT_OK) { bc.items.clear(); bc.items_pk.clear(); for (uint32_t k = 0; k <= i; k++) scenes[k]->ctr_dirty = true; return rc; }   // held frames are dropped: their counter sets may be half-used
     }
-    if (!bc.items_pk.empty()) {
-        const size_t held_pk = bc.items_pk.size();
-        const FrameItem* table = nullptr;
-        int rc = frame_table(scenes[0], bc.items_pk, stream, &table);
-        const dim3 block(256), g8((bc.wl + 7) / 8, (bc.rows + 7) / 8, (uint32_t)held_pk), g16((bc.wl + 15) / 16, (bc.rows + 15) / 16, (uint32_t)held_pk);
+    // the held frames, FRAME_TAB_MAX at a time: their arguments by value in the launch (srt_kernels.h: FrameTab)
+    int rc = SRT_OK;
+    const dim3 block(256);
+    for (size_t first = 0; first < bc.items_pk.size() && rc == SRT_OK; first += FRAME_TAB_MAX) {
+        const uint32_t held_pk = (uint32_t)std::min<size_t>(FRAME_TAB_MAX, bc.items_pk.size() - first);
+        FrameTab tab;
+        std::memset(&tab, 0, sizeof(tab));
+        std::memcpy(tab.it, bc.items_pk.data() + first, held_pk * sizeof(FrameItem));
+        const dim3 g8((bc.wl + 7) / 8, (bc.rows + 7) / 8, held_pk), g16((bc.wl + 15) / 16, (bc.rows + 15) / 16, held_pk);
         const uint64_t n_tiles = (uint64_t)g8.x * g8.y, max_units = n_tiles * 4u * 2u * ((bc.max_lights + 7) / 8);
-        uint64_t wgs_all = (uint64_t)scenes[0]->n_cu * 8;               // the chip's worth of waves, shared by the frames
+        const uint64_t wgs_all = (uint64_t)scenes[0]->n_cu * 8;         // the chip's worth of waves, shared by the frames
         uint32_t wgs = (uint32_t)((wgs_all + held_pk - 1) / held_pk);
         if ((uint64_t)wgs > max_units / 4 + 1) wgs = (uint32_t)(max_units / 4 + 1);
-        if (rc == SRT_OK && table) {
-            hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true>), g8, block, 0, stream, table);
-            hipLaunchKernelGGL((k_shadow_pk_batch<true>), dim3(wgs, (uint32_t)held_pk), block, 0, stream, table);
-            if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g16, block, 0, stream, table);
-            else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g16, block, 0, stream, table);
-            if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
-        } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
-            const uint32_t wgs1 = (uint32_t)(max_units / 4 + 1 < wgs_all ? max_units / 4 + 1 : wgs_all);
-            for (const FrameItem& it : bc.items_pk) {
-                hipLaunchKernelGGL((k_closest_hit_nq<false, 512, 2, 2, true, false, false, 7>), dim3(g8.x, g8.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, it.qcount, it.qlist, it.qcap);
-                hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs1), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
-                hipLaunchKernelGGL(k_shade_tile<0>, dim3(g16.x, g16.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
-                if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
-            }
-        }
-        if (rc != SRT_OK) { for (uint32_t k = 0; k < n; k++) scenes[k]->ctr_dirty = true; return rc; }
-    }
-    const size_t held = bc.items.size();
-    if (!held) return SRT_OK;
-    const FrameItem* table = nullptr;
-    int rc = frame_table(scenes[0], bc.items, stream, &table);
-    const dim3 block(256), g_trace((bc.wl + 7) / 8, (bc.rows + 7) / 8, (uint32_t)held), g_shade((bc.wl + 15) / 16, (bc.rows + 15) / 16, (uint32_t)held);
-    if (rc == SRT_OK && table) {
-        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 7, 16>), g_trace, block, 0, stream, table);
+        hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true>), g8, block, 0, stream, tab);
+        hipLaunchKernelGGL((k_shadow_pk_batch<true>), dim3(wgs, held_pk), block, 0, stream, tab);
+        if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g16, block, 0, stream, tab);
+        else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g16, block, 0, stream, tab);
         if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
-        if (rc == SRT_OK) {
-            if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g_shade, block, 0, stream, table);
-            else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g_shade, block, 0, stream, table);
-            if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
-        }
-    } else if (rc == SRT_OK) {            // no table may be made while the stream captures: the same frames, one by one
-        for (const FrameItem& it : bc.items) {
-            hipLaunchKernelGGL((k_trace_nq<false, 512, true, 7, 16>), dim3(g_trace.x, g_trace.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
-            hipLaunchKernelGGL(k_shade_tile<0>, dim3(g_shade.x, g_shade.y), block, 0, stream, it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
-            if (hipGetLastError() != hipSuccess) { rc = SRT_ERR_DEVICE; break; }
-        }
+    }
+    for (size_t first = 0; first < bc.items.size() && rc == SRT_OK; first += FRAME_TAB_MAX) {
+        const uint32_t held = (uint32_t)std::min<size_t>(FRAME_TAB_MAX, bc.items.size() - first);
+        FrameTab tab;
+        std::memset(&tab, 0, sizeof(tab));
+        std::memcpy(tab.it, bc.items.data() + first, held * sizeof(FrameItem));
+        const dim3 g_trace((bc.wl + 7) / 8, (bc.rows + 7) / 8, held), g_shade((bc.wl + 15) / 16, (bc.rows + 15) / 16, held);
+        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 7, 16>), g_trace, block, 0, stream, tab);
+        if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g_shade, block, 0, stream, tab);
+        else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g_shade, block, 0, stream, tab);
+        if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;
     }
     if (rc != SRT_OK) for (uint32_t k = 0; k < n; k++) scenes[k]->ctr_dirty = true;       // the set the shading would have zeroed
     return rc;
@@ -1292,6 +1237,14 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
         if (std::getenv("SRT_DIAG_COUNTERS"))      // counting build of the packet shadow kernel: shape of its walks
             std::fprintf(stderr, "srt diag: walks %llu steps %llu node-window loads %llu triangle iterations %llu | lane tests: nodes %llu tris %llu\n",
                          s->h_counters[0], s->h_counters[5], s->h_counters[6], s->h_counters[7], s->h_counters[3], s->h_counters[4]);
+        if (std::getenv("SRT_DIAG_COUNTERS") && s->h_counters[17]) {
+            const double span = (double)(s->h_counters[10] - ((1ull << 62) - s->h_counters[11])) * 0.01;      // us
+            std::fprintf(stderr, "srt diag: packet shadow kernel: %llu waves, first start to last end %.1f us, mean wave busy %.1f us (%.0f %%), longest walk %.1f us, "
+                                 "most steps in a walk %llu, walks of > 256 steps %llu (mean %.1f us)\n",
+                         s->h_counters[17], span, (double)s->h_counters[9] * 0.01 / (double)s->h_counters[17],
+                         span > 0 ? 100.0 * (double)s->h_counters[9] * 0.01 / (double)s->h_counters[17] / span : 0.0, (double)s->h_counters[12] * 0.01,
+                         s->h_counters[13], s->h_counters[14], s->h_counters[14] ? (double)s->h_counters[15] * 0.01 / (double)s->h_counters[14] : 0.0);
+        }
         s->pending = false;
     }
     if (stats) *stats = s->last;

@@ -1599,10 +1599,22 @@ struct FrameItem {
     uint32_t* qlist; uint32_t qcap, pad_;      // the frame's quadrant list (8+-sample pipeline)
 };
 static_assert(sizeof(FrameItem) == sizeof(DevScene) + sizeof(DevParams) + 9 * 8 + 8, "FrameItem has no implicit padding");
+// The frames' arguments travel BY VALUE, in the kernel-argument segment (round 3).  Rounds 1-2 kept the table in device memory; a pointer
+// that comes out of memory is a GENERIC pointer to the compiler, every access through it a flat_load / flat_store (both wait counters,
+// no scalar form), where the same body with its arguments by value reads wave-uniform records with s_load and the rest with
+// global_load -- measured on K4 with one whole frame per "batch": k_shadow_pk_batch 1.57 ms against k_shadow_pk 1.10, closest hit 0.257
+// against 0.219, shading 0.135 against 0.122.  Pointer members of a by-value kernel argument are global pointers to the compiler
+// (also behind a dynamic index), nothing has to be allocated, copied or kept alive for a captured graph.  The segment is ordinary
+// memory on this stack (a 26 KB argument was launched and read back on the MI355X; there is no 4 KB ceiling as on other runtimes):
+// 40 frames = 16 KB a launch, a batch of more is issued as several launches -- and every launch boundary costs: the 36 share-frames of a
+// K3 step at N = 8 in five launches of 8 took 0.81 ms a step, in one launch 0.64.
+constexpr uint32_t FRAME_TAB_MAX = 40;
+struct FrameTab { FrameItem it[FRAME_TAB_MAX]; };
+static_assert(sizeof(FrameTab) <= 16384, "the frame table is copied into the kernel-argument segment at every launch");
 // the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)
 template <int NQCAP, bool FILTER>
-__global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameItem* __restrict__ items) {
-    const FrameItem it = items[blockIdx.z];
+__global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameTab tab) {
+    const FrameItem& it = tab.it[blockIdx.z];
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][NQ_P];
@@ -1618,8 +1630,8 @@ __global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameItem
 }
 
 template <int NQCAP, bool FILTER, int MINW, int RS>
-__global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameItem* __restrict__ items) {
-    const FrameItem it = items[blockIdx.z];
+__global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameTab tab) {
+    const FrameItem& it = tab.it[blockIdx.z];
     trace_nq_body<false, NQCAP, FILTER, RS, false, false>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
 }
 
@@ -1676,8 +1688,8 @@ __global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile(DevScene s
     shade_tile_body<INT_SHIN != 0>(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount);
 }
 template <int INT_SHIN>
-__global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile_batch(const FrameItem* __restrict__ items) {      // the shading of the frames k_trace_nq_batch traced
-    const FrameItem it = items[blockIdx.z];
+__global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile_batch(const FrameTab tab) {      // the shading of the frames k_trace_nq_batch traced
+    const FrameItem& it = tab.it[blockIdx.z];
     shade_tile_body<INT_SHIN != 0>(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
 }
 

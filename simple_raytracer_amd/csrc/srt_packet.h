@@ -43,7 +43,16 @@ __device__ __forceinline__ bool packet_slab(V3 o, V3 d, RayRcp rc, const DevNode
 // ---- any-hit packet walk (shadowIntersection:321-342) -----------------------------------------------------------------
 // valid lanes carry a shadow ray (origin ro = d*t, direction rd = L - d*t, :325-326) and the node range `self` of the hit
 // object, which the walk jumps over (the reference walks it and discards the result, :328/:331).  Returns "shadowed".
-template <bool COUNT, bool FILTER>
+//
+// PF > 0: the successors' records requested AHEAD.  A step of the plain form is a chain  record load -> slab test -> ballot -> next
+// record load (-> triangle load -> test -> next triangle load ...): ~860 cycles, most of it the two scalar round trips, and a walk
+// through a tree crown is 300-500 such steps in a row -- the launch ends when the last of them does (counting build: wave slots 71 %
+// busy on K4, 44 % on an eighth of it).  The walk only ever continues at i + 1 (some lane passed, or a leaf), at skip[i] (no lane
+// passed) or, rarely, further on (every lane at the successor dropped out); so the record of i + 1 (PF >= 1), the record of skip[i] of
+// an inner node and the first triangle of a leaf (PF >= 2) are requested at the TOP of the step, while the slab test of node i runs,
+// and the next triangle of a leaf while the current one is tested.  Same visits, same tests, same order: only loads that may turn out
+// unused (clamped into the arrays).
+template <bool COUNT, bool FILTER, int PF = 0>
 __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self,
                                                unsigned long long& n_node, unsigned long long& n_tri, unsigned long long* diag = nullptr) {
     const uint32_t N = s.n_nodes;
@@ -52,6 +61,69 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
     if (n == (uint32_t)self.x) n = (uint32_t)self.y;
     bool flag = false;
     uint32_t i = wave_min_u32(n);
+    if (PF > 0) {
+        // records as float4 pairs / triples (plain vector types: the compiler keeps them in SGPRs; copies of the structs did not)
+        const float4* const n4 = reinterpret_cast<const float4*>(s.nodes);
+        const float4* const t4 = reinterpret_cast<const float4*>(s.tris);
+        const uint32_t last = N - 1u;
+        const uint32_t i0 = i < N ? i : last;
+        float4 na = n4[2 * (size_t)i0], nb = n4[2 * (size_t)i0 + 1];
+        // scalar loads return out of order, so the only wait there is is "all of them": every way into a step must arrive with nothing
+        // outstanding, or the compiler has to put that wait right behind the requests at the top of the step (it did) and nothing overlaps
+        // (an empty asm the record passes THROUGH makes the compiler wait there; the s_waitcnt builtin and a volatile asm count as memory
+        // clobbers and turn every record load of the walk into a vector load)
+#define SRT_ARRIVED(a, b) asm("" : "+s"((a).x), "+s"((a).y), "+s"((a).z), "+s"((a).w), "+s"((b).x), "+s"((b).y), "+s"((b).z), "+s"((b).w))
+        SRT_ARRIVED(na, nb);
+        while (i < N) {
+            const uint32_t i1 = i < last ? i + 1u : last;
+            const int32_t skip = __float_as_int(nb.z), leaf = __float_as_int(nb.w);
+            const bool is_leaf = leaf >= 0;
+            const uint32_t first = (uint32_t)leaf >> LEAF_SHIFT, cnt = is_leaf ? (uint32_t)leaf & LEAF_MAX : 0u;
+            float4 ya = make_float4(0.f, 0.f, 0.f, 0.f), yb = ya;            // inner node: record of skip[i]; leaf: first triangle (ya, yb, yc)
+            float yc = 0.f;
+            if (PF >= 2) {
+                if (is_leaf) { if (cnt) { ya = t4[3 * (size_t)first]; yb = t4[3 * (size_t)first + 1]; yc = t4[3 * (size_t)first + 2].x; } }
+                else { const uint32_t sk = (uint32_t)skip < N ? (uint32_t)skip : last; ya = n4[2 * (size_t)sk]; yb = n4[2 * (size_t)sk + 1]; }
+            }
+            const float4 xa = n4[2 * (size_t)i1], xb = n4[2 * (size_t)i1 + 1];           // record of i + 1
+            const bool act = n == i;
+            bool pass = false;
+            if (act) {
+                if (FILTER) {
+                    bool amb;
+                    pass = ray_aabb_filtered(ro, rc, na.x, na.y, na.z, na.w, nb.x, nb.y, amb);
+                    if (amb) pass = ray_aabb_nb(ro, rd, na.x, na.y, na.z, na.w, nb.x, nb.y);
+                } else pass = ray_aabb_nb(ro, rd, na.x, na.y, na.z, na.w, nb.x, nb.y);
+            }
+            uint32_t cand;
+            if (is_leaf) {
+                bool todo = pass;
+                if (PF < 2 && cnt && __ballot(todo)) { ya = t4[3 * (size_t)first]; yb = t4[3 * (size_t)first + 1]; yc = t4[3 * (size_t)first + 2].x; }
+                for (uint32_t k = 0; k < cnt && __ballot(todo); k++) {
+                    float4 za = ya, zb = yb; float zc = yc;
+                    if (k + 1u < cnt) { const size_t j = 3 * (size_t)(first + k + 1u); za = t4[j]; zb = t4[j + 1]; zc = t4[j + 2].x; }      // in flight during this triangle's test
+                    if (todo) {
+                        const float t = ray_triangle(ro, rd, mk(ya.x, ya.y, ya.z), mk(ya.w, yb.x, yb.y), mk(yb.z, yb.w, yc));
+                        if (t != SRT_NEG_INF) { flag = true; todo = false; }      // any t >= 0, NaN included (:335)
+                    }
+                    ya = za; yb = zb; yc = zc;
+                }
+                if (act) n = flag ? N : i + 1u;
+                cand = i + 1u;
+            } else {
+                if (act) n = pass ? i + 1u : (uint32_t)skip;
+                cand = __ballot(pass) ? i + 1u : (uint32_t)skip;
+            }
+            if (n == (uint32_t)self.x) n = (uint32_t)self.y;        // never the hit object's own tree
+            const uint32_t inext = __ballot(n == cand) ? cand : wave_min_u32(n);
+            if (inext == i + 1u) { na = xa; nb = xb; }
+            else if (PF >= 2 && !is_leaf && inext == (uint32_t)skip) { na = ya; nb = yb; }
+            else if (inext < N) { na = n4[2 * (size_t)inext]; nb = n4[2 * (size_t)inext + 1]; SRT_ARRIVED(na, nb); }
+            i = inext;
+        }
+#undef SRT_ARRIVED
+        return flag;
+    }
     while (i < N) {
         const DevNode nd = s.nodes[i];                          // wave-uniform index: one request per wave
         if (COUNT && diag) diag[0]++;
@@ -304,7 +376,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
 // =================================================================================================
 // qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) units handed out per fetch shard; counters
 // QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
-template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR>
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR, int PF = 0>
 __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParams& p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
                                                unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
@@ -329,6 +401,9 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
     uint32_t home = (blockIdx.x * 4u + wave) & (QL_SHARDS - 1);
     uint32_t k_next = 0;
+    // counting build: when this wave started, and what its longest walk was (10 ns ticks of the constant clock)
+    const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long w_max = 0, w_max_steps = 0, w_long = 0, w_long_ticks = 0;
     if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
     for (;;) {
         const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
@@ -378,10 +453,23 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
         }
         if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
         if (COUNT) diag[4]++;
+        const unsigned long long w0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull, st0 = diag[0];
         const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, win_all[wave], nbase, tbase, n_node, n_tri, diag)
-                                      : packet_any_hit<COUNT, FILTER>(s, valid, so, sd, self, n_node, n_tri, diag);
+                                      : packet_any_hit<COUNT, FILTER, PF>(s, valid, so, sd, self, n_node, n_tri, diag);
         const unsigned long long sm = __ballot(shadowed);
         if (valid && lg == 0) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)(sm >> (pr * 8u));
+        if (COUNT) {
+            const unsigned long long w = __builtin_amdgcn_s_memrealtime() - w0, st = diag[0] - st0;
+            if (w > w_max) w_max = w;
+            if (st > w_max_steps) w_max_steps = st;
+            if (st > 256) { w_long++; w_long_ticks += w; }
+        }
+    }
+    if (COUNT && lane == 0) {      // slots 9..15 and 17..19 are free between the hit shards
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(counters + 9, t_end - t_begin); atomicMax(counters + 10, t_end); atomicMax(counters + 11, (1ull << 62) - t_begin);
+        atomicMax(counters + 12, w_max); atomicMax(counters + 13, w_max_steps); atomicAdd(counters + 14, w_long); atomicAdd(counters + 15, w_long_ticks);
+        atomicAdd(counters + 17, 1ull);
     }
     if (COUNT) {
         wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri);
@@ -390,15 +478,15 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     }
 }
 
-template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false>
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false, int PF = 0>
 __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                    uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
                                                    unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
-    shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
+    shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR, PF>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
 }
 // the frames of a batch (srt_render_device_batch): blockIdx.y = frame, gridDim.x waves-of-four pull the units of THAT frame's list
 template <bool FILTER>
-__global__ __launch_bounds__(256, 8) void k_shadow_pk_batch(const FrameItem* __restrict__ items) {
-    const FrameItem it = items[blockIdx.y];
+__global__ __launch_bounds__(256, 8) void k_shadow_pk_batch(const FrameTab tab) {
+    const FrameItem& it = tab.it[blockIdx.y];
     shadow_pk_body<false, FILTER, false, false>(it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
 }

@@ -766,6 +766,28 @@ def test_kernel_variants_agree(srt, oracle, variant, name, W, H, L):
     assert np.array_equal(bits(e["rgb_linear"]), bits(o["rgb_linear"])) and np.array_equal(e["rgb8"], o["rgb8"])
 
 
+@pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 192, 108, 16), ("k4", 240, 135, 20), ("main_nocats", 160, 90, 64), ("cubes4_a40", 150, 100, 17),
+                                        ("cube", 37, 23, 16)])
+def test_packet_shadow_walk_with_records_requested_ahead(srt, oracle, name, W, H, L):
+    """k_shadow_pk with the successors' records (i + 1; skip[i] / the leaf's first triangle; the next triangle) requested at the top of
+    a step: the same walk -- shadow bits, colours and hits bit for bit those of the plain form (variant 57) and of the oracle, whole
+    frames and a scanline-block share."""
+    g, ds = device_scene(srt, name)
+    for kw in ({}, dict(block_rows=8, block_first=1, block_stride=3)):
+        c = oracle.render(g.flat, g.params(W, H, L, **kw))
+        outs = {}
+        for variant in (0, 55, 56, 57):
+            o = ds.render(g.params(W, H, L, flags=variant << 8, **kw))
+            assert "k_shadow_pk" in ds.pipeline, ds.pipeline
+            assert np.array_equal(o["hit_id"], c["hit_id"]) and np.array_equal(bits(o["t"]), bits(c["t"]))
+            outs[variant] = o
+        for variant in (55, 56, 57):
+            assert np.array_equal(bits(outs[variant]["rgb_linear"]), bits(outs[0]["rgb_linear"])), variant
+            assert np.array_equal(outs[variant]["rgb8"], outs[0]["rgb8"]), variant
+        fin = np.isfinite(c["rgb_linear"]).all(-1)
+        assert float(np.abs(outs[0]["rgb_linear"][fin] - c["rgb_linear"][fin]).max()) < 1e-4
+
+
 @pytest.mark.parametrize("name,W,H,L", [("ground_bunny", 190, 107, 1), ("cubes4_a0", 128, 96, 3), ("texquad", 64, 48, 2), ("cubes4_a40", 150, 100, 7),
                                         ("spheres6", 160, 120, 1)])
 def test_frame_in_one_launch_matches_two_launches(srt, name, W, H, L):
