@@ -425,8 +425,8 @@ static int check_desc(const srt_scene_desc* d) {
 static hipError_t init_handle_state(srt_scene* s) {
     hipError_t e = hipMalloc((void**)&s->d_counters, 2 * NCTR * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_qcount, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_qcount, QL_COUNTERS * QL_STRIDE * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(s->d_qcount, 0, QL_COUNTERS * QL_STRIDE * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counters, NCTR * sizeof(unsigned long long), hipHostMallocDefault);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, s->device);
@@ -873,7 +873,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // a render that failed half-way may have left either set dirty: clear both before the next one
     if (s->ctr_dirty) {
         HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * NCTR * sizeof(unsigned long long), stream));
-        HIP_TRY(hipMemsetAsync(s->d_qcount, 0, 2 * QL_SHARDS * QL_STRIDE * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(s->d_qcount, 0, QL_COUNTERS * QL_STRIDE * sizeof(uint32_t), stream));
     }
     s->ctr_dirty = true;
     // a counting run must not inherit whatever replayed graphs left in the set (their frames use fixed sets)
@@ -904,8 +904,14 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
-    dp.pad2_ = 0u;
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 58)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    // packet shadow walks of this many node steps put their quadrant on the heavy list of the next frame (srt_kernels.h).  Only for frames
+    // of a BATCH call: there the frames' shadow rays are one launch and its tail is idle machine (a K4 step of eight share-frames 2.24 ->
+    // 1.73 ms).  Frames launched one by one on several streams pipeline -- the next frame's closest-hit launch fills the slots a tail
+    // frees -- and lose that when the launch ends abruptly (K4 on four streams 10.1 -> 10.5-11.1 ms per 8 frames, K3 with 16 samples
+    // 3.38 -> 3.6-4.0; one stream: no difference), so they keep the plain order.  SRT_HEAVY_STEPS overrides (0 = off).
+    static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
+    dp.heavy_steps = (bc && variant != 59) ? heavy_default : 0u;
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 59)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -925,7 +931,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         HIP_TRY(wait_idle(s));
         if (s->ws_qlist) (void)hipFree(s->ws_qlist);
         s->ws_qlist = nullptr; s->qcap = 0;
-        HIP_TRY(hipMalloc((void**)&s->ws_qlist, (size_t)QL_SHARDS * qcap_need * 2 * sizeof(uint32_t)));      // two words per entry
+        // two words per entry, and behind the lists one word per quadrant: the cost map the shadow kernel leaves for the next frame's list
+        HIP_TRY(hipMalloc((void**)&s->ws_qlist, (size_t)QL_SHARDS * qcap_need * 3 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->ws_qlist + (size_t)QL_SHARDS * qcap_need * 2, 0, (size_t)QL_SHARDS * qcap_need * sizeof(uint32_t)));
         s->qcap = qcap_need;
     }
     if (spp > 1 && s->ws_acc_pixels < pixels) {                    // supersampling extension: accumulation buffers
@@ -1064,6 +1072,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
             else if ((p->flags >> 8 & 0xffu) == 55)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // record of i + 1 requested ahead (A/B)
             else if ((p->flags >> 8 & 0xffu) == 56)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 2>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // + skip[i] / first triangle (A/B)
+            else if ((p->flags >> 8 & 0xffu) == 58)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, -1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // the shipped walk with wave clocks (SRT_DIAG_COUNTERS)
             else if ((p->flags >> 8 & 0xffu) == 57)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 0>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // the plain walk (A/B)
             else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // records through LDS windows (A/B)
             else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
@@ -1244,6 +1253,7 @@ int srt_sync(srt_scene* s, srt_stats* stats) {
                          s->h_counters[17], span, (double)s->h_counters[9] * 0.01 / (double)s->h_counters[17],
                          span > 0 ? 100.0 * (double)s->h_counters[9] * 0.01 / (double)s->h_counters[17] / span : 0.0, (double)s->h_counters[12] * 0.01,
                          s->h_counters[13], s->h_counters[14], s->h_counters[14] ? (double)s->h_counters[15] * 0.01 / (double)s->h_counters[14] : 0.0);
+            std::fprintf(stderr, "srt diag: walks of 100 us and more: %llu\n", s->h_counters[18]);
         }
         s->pending = false;
     }

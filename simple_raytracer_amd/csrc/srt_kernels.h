@@ -55,7 +55,7 @@ struct DevParams {
     uint32_t shadow_px_major;     // shadow bits as the packet shadow kernel writes them: per pixel one u64 per 64 light samples
     uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
     float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
-    uint32_t exp, pad2_;          // experiment switches (A/B variants, wave-uniform branches): bit 0 = queue pushes in LANE order (the round-2 form) instead of node-major
+    uint32_t exp, heavy_steps;    // heavy_steps: packet shadow walks of that many steps make their quadrant a HEAVY one in the next frame's list (0 = off).  exp: experiment switches (A/B variants, wave-uniform branches): bit 0 = queue pushes in LANE order (the round-2 form) instead of node-major
 };
 static_assert(sizeof(DevParams) == 152, "DevParams has no implicit padding");
 
@@ -316,11 +316,34 @@ constexpr int QL_SHARDS = 64;            // shard lists; a quadrant goes to shar
 constexpr int QL_STRIDE = 16;            // counters 64 B apart
 // entry = two words: tile index << 2 | quadrant, and the quadrant's 16-bit hit mask (bit = y * 4 + x).  Called by one lane of a
 // wave whose quadrant has a hit.
+//
+// HEAVY quadrants first (round 3).  The packet shadow kernel's launch ends when its longest walk does: a walk through a tree crown
+// is 300-500 dependent steps (~0.3 ms), most walks are a dozen, and the quadrants arrive in the order the closest-hit waves happen to
+// finish -- so some long walks start when the launch is nearly over (SQ_WAVE_CYCLES: the kernel's 8,192 wave slots are 70 % busy on the
+// K4 frame, 45 % on an eighth of it).  A quadrant's walks are as long in the next frame as in this one (an orbit moves the picture by
+// a few pixels, a benchmark not at all), so the shadow kernel leaves the step count of a quadrant's longest walk in a cost map
+// (one word per quadrant, behind the list: qlist + 2 * QL_SHARDS * qcap words), and the NEXT frame's append reads it (and clears it):
+// quadrants at or above heavy_steps grow from the END of their shard's array (own counters, [2 * QL_SHARDS, 3 * QL_SHARDS)), and the
+// shadow kernel deals all units of the heavy entries before any other.  Order only: every unit still owns its bytes of the result.
+constexpr int QL_COUNTERS = 3 * QL_SHARDS;      // list lengths | units handed out | heavy-list lengths
+__device__ __forceinline__ uint32_t* quadrant_cost_map(uint32_t* qlist, uint32_t qcap) { return qlist + 2u * (size_t)QL_SHARDS * qcap; }
 __device__ __forceinline__ void quadrant_list_append(uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap,
-                                                     uint32_t tile_index, uint32_t quadrant, uint32_t hit_mask) {
-    const uint32_t shard = tile_index & (QL_SHARDS - 1);
-    const uint32_t slot = atomicAdd(qcount + shard * QL_STRIDE, 1u);
-    if (slot < qcap) reinterpret_cast<uint2*>(qlist)[(size_t)shard * qcap + slot] = make_uint2((tile_index << 2) | quadrant, hit_mask);
+                                                     uint32_t tile_index, uint32_t quadrant, uint32_t hit_mask, uint32_t heavy_steps) {
+    const uint32_t shard = tile_index & (QL_SHARDS - 1), key = (tile_index << 2) | quadrant;
+    bool heavy = false;
+    if (heavy_steps) {
+        uint32_t* const cost = quadrant_cost_map(qlist, qcap) + key;       // key < 4 * tiles <= QL_SHARDS * qcap
+        const uint32_t c = *cost;
+        heavy = c >= heavy_steps;
+        if (c) *cost = 0u;
+    }
+    if (heavy) {
+        const uint32_t slot = atomicAdd(qcount + (2 * QL_SHARDS + shard) * QL_STRIDE, 1u);
+        if (slot < qcap) reinterpret_cast<uint2*>(qlist)[(size_t)shard * qcap + (qcap - 1u - slot)] = make_uint2(key, hit_mask);
+    } else {
+        const uint32_t slot = atomicAdd(qcount + shard * QL_STRIDE, 1u);
+        if (slot < qcap) reinterpret_cast<uint2*>(qlist)[(size_t)shard * qcap + slot] = make_uint2(key, hit_mask);
+    }
 }
 
 constexpr int NQ_P = 16;                    // rays per wavefront of the shadow kernel (4x4 pixel quadrant)
@@ -753,7 +776,7 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
     count_hits(counters, is_hit, by * gx + bx);
     if (TWL == 2 && THL == 2 && qlist) {
         const unsigned long long hm = __ballot(is_hit);          // all lanes vote: not inside the lane-0 branch
-        if (lane == 0 && hm) quadrant_list_append(qcount, qlist, qcap, by * gx + bx, wave, (uint32_t)hm);
+        if (lane == 0 && hm) quadrant_list_append(qcount, qlist, qcap, by * gx + bx, wave, (uint32_t)hm, p.heavy_steps);
     }
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
@@ -1513,7 +1536,7 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     if (SHADE) {
         if (threadIdx.x == 0) fin_count = 0u;              // (the barrier in finish_background_tile orders this before the first bump)
         if (counters_next) zero_next_counters(counters_next);
-        if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;
+        if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < QL_COUNTERS) qcount[threadIdx.x * QL_STRIDE] = 0u;
     }
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
@@ -1649,7 +1672,7 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
                                                 unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
     if (counters_next) zero_next_counters(counters_next);
     // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
-    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * QL_SHARDS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
+    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < QL_COUNTERS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
 #ifdef SRT_DIAG
     rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
 #endif

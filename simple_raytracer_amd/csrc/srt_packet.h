@@ -53,8 +53,9 @@ __device__ __forceinline__ bool packet_slab(V3 o, V3 d, RayRcp rc, const DevNode
 // and the next triangle of a leaf while the current one is tested.  Same visits, same tests, same order: only loads that may turn out
 // unused (clamped into the arrays).
 template <bool COUNT, bool FILTER, int PF = 0>
-__device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self,
+__device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self, uint32_t& steps,
                                                unsigned long long& n_node, unsigned long long& n_tri, unsigned long long* diag = nullptr) {
+    steps = 0u;                                              // node steps of this walk (wave-uniform): what makes a quadrant a heavy one
     const uint32_t N = s.n_nodes;
     const RayRcp rc = ray_rcp(rd);
     uint32_t n = valid ? 0u : N;
@@ -75,6 +76,7 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
 #define SRT_ARRIVED(a, b) asm("" : "+s"((a).x), "+s"((a).y), "+s"((a).z), "+s"((a).w), "+s"((b).x), "+s"((b).y), "+s"((b).z), "+s"((b).w))
         SRT_ARRIVED(na, nb);
         while (i < N) {
+            steps++;
             const uint32_t i1 = i < last ? i + 1u : last;
             const int32_t skip = __float_as_int(nb.z), leaf = __float_as_int(nb.w);
             const bool is_leaf = leaf >= 0;
@@ -126,6 +128,7 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
     }
     while (i < N) {
         const DevNode nd = s.nodes[i];                          // wave-uniform index: one request per wave
+        steps++;
         if (COUNT && diag) diag[0]++;
         const bool act = n == i;
         bool pass = false;
@@ -171,10 +174,11 @@ struct PkWindows {
     float4 t0[64], t1[64], t2[64];       // triangles base .. base + 63 (DevTri)
 };
 template <bool COUNT, bool FILTER>
-__device__ __forceinline__ bool packet_any_hit_win(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self, PkWindows& w,
+__device__ __forceinline__ bool packet_any_hit_win(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self, uint32_t& steps, PkWindows& w,
                                                    uint32_t& nbase, uint32_t& tbase, unsigned long long& n_node, unsigned long long& n_tri,
                                                    unsigned long long* diag = nullptr) {      // counting build: [0] steps [1] node-window loads [2] triangle iterations [3] triangle-window loads
     const uint32_t N = s.n_nodes, NT = s.n_tris;
+    steps = 0u;
     const uint32_t lane = threadIdx.x & 63;
     const float4* nodes4 = reinterpret_cast<const float4*>(s.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(s.tris);
@@ -192,6 +196,7 @@ __device__ __forceinline__ bool packet_any_hit_win(const DevScene& s, bool valid
             if (COUNT && diag) diag[1]++;
         }
         const float4 a = w.na[i - nbase], b = w.nb[i - nbase];   // wave-uniform address: broadcast
+        steps++;
         if (COUNT && diag) diag[0]++;
         const int32_t skip = __builtin_amdgcn_readfirstlane(__float_as_int(b.z)), leaf = __builtin_amdgcn_readfirstlane(__float_as_int(b.w));
         const bool act = n == i;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
         const uint32_t tile_index = by * tiles_x + bx;
         atomicAdd(counters + CTR_HIT_BASE + 8 * (tile_index & (HIT_SHARDS - 1)), (unsigned long long)__popcll(hm));
         if (qlist)
-            for (uint32_t q = 0; q < 4; q++) if ((hm >> (16 * q)) & 0xffffull) quadrant_list_append(qcount, qlist, qcap, tile_index, q, (uint32_t)(hm >> (16 * q)) & 0xffffu);
+            for (uint32_t q = 0; q < 4; q++) if ((hm >> (16 * q)) & 0xffffull) quadrant_list_append(qcount, qlist, qcap, tile_index, q, (uint32_t)(hm >> (16 * q)) & 0xffffu, p.heavy_steps);
     }
     if (COUNT) { wave_add(counters + 1, n_node); wave_add(counters + 2, n_tri); }
 }
@@ -388,22 +393,29 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const uint32_t n_lc8 = (p.n_lights + 7u) >> 3;                        // chunks of 8 light samples = bytes per pixel
     const uint32_t upe = 2u * n_lc8;                                      // units per entry: two groups of 8 hit ranks x the chunks
     const uint32_t pr = lane >> 3, lg = lane & 7u;                        // this lane's pixel slot and light sample within a walk
-    // prefix sum over the shard list lengths: lane k holds shard k
-    uint32_t cnt = qcount[lane * QL_STRIDE];
-    cnt = cnt < qcap ? cnt : qcap;
-    uint32_t incl = cnt;
+    // prefix sums over the shard list lengths, heavy lists and the others: lane k holds shard k
+    uint32_t cnt = qcount[lane * QL_STRIDE], cnt_h = qcount[(2 * QL_SHARDS + lane) * QL_STRIDE];
+    cnt = cnt < qcap ? cnt : qcap; cnt_h = cnt_h < qcap ? cnt_h : qcap;
+    uint32_t incl = cnt, incl_h = cnt_h;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
-    const uint32_t n_entries = (uint32_t)__shfl((int)incl, 63, 64);
-    const uint32_t n_units = n_entries * upe;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64), oh = (uint32_t)__shfl_up((int)incl_h, off, 64);
+        if (lane >= (uint32_t)off) { incl += o; incl_h += oh; }
+    }
+    const uint32_t n_rest = (uint32_t)__shfl((int)incl, 63, 64), n_heavy = (uint32_t)__shfl((int)incl_h, 63, 64);
+    const uint32_t n_units = (n_rest + n_heavy) * upe, units_h = n_heavy * upe;        // the heavy entries' units come first
+    uint32_t* const cost_map = quadrant_cost_map(const_cast<uint32_t*>(qlist), qcap);
+    const uint32_t every = units_h && n_units / (2u * units_h) > 1u ? n_units / (2u * units_h) : 1u;
     uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
     uint32_t home = (blockIdx.x * 4u + wave) & (QL_SHARDS - 1);
     uint32_t k_next = 0;
     // counting build: when this wave started, and what its longest walk was (10 ns ticks of the constant clock)
-    const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    constexpr bool TIMING = COUNT || PF < 0;          // PF < 0: the plain walk of the shipped build with the wave clocks of the counting build
+    const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long w_max = 0, w_max_steps = 0, w_long = 0, w_long_ticks = 0;
+    uint32_t w_slow = 0;                                          // walks of 100 us and more
     if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
     for (;;) {
         const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
@@ -422,12 +434,20 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
         // unit -> (chunk of 8 samples, entry, pixel group): consecutive units are different ENTRIES, so that the waves that
         // start together do not all read the same quadrant
         uint32_t lc, g, e;
-        if (ENTRY_MAJOR) { e = u / upe; const uint32_t w_ = u - e * upe; lc = w_ >> 1; g = w_ & 1u; }
-        else { lc = u / (2u * n_entries); const uint32_t ue = u - lc * 2u * n_entries; g = ue / n_entries; e = ue - g * n_entries; }
-        const unsigned long long above = __ballot(incl > e);                 // first shard list whose inclusive prefix exceeds e
+        // heavy units are dealt EARLY but not all at once: one in every `every` units until they are used up, by about the middle of
+        // the launch (all of them first was measured too: a share of a frame gained as much, but whole frames on four streams LOST 7-15 % --
+        // a launch that opens with nothing but long latency-bound walks and closes with nothing but short issue-bound ones uses
+        // the machine worse than the mix)
+        const uint32_t hslot = u / every;
+        const bool hv = hslot < units_h && hslot * every == u;               // wave-uniform
+        const uint32_t uu = hv ? hslot : u - (hslot < units_h ? hslot + 1u : units_h), n_entries = hv ? n_heavy : n_rest;
+        if (ENTRY_MAJOR) { e = uu / upe; const uint32_t w_ = uu - e * upe; lc = w_ >> 1; g = w_ & 1u; }
+        else { lc = uu / (2u * n_entries); const uint32_t ue = uu - lc * 2u * n_entries; g = ue / n_entries; e = ue - g * n_entries; }
+        const uint32_t incl_c = hv ? incl_h : incl, cnt_c = hv ? cnt_h : cnt;
+        const unsigned long long above = __ballot(incl_c > e);               // first shard list whose inclusive prefix exceeds e
         const uint32_t shard = (uint32_t)__builtin_ctzll(above);
-        const uint32_t excl = (uint32_t)__shfl((int)(incl - cnt), (int)shard, 64);
-        const uint2 ent = reinterpret_cast<const uint2*>(qlist)[(size_t)shard * qcap + (e - excl)];      // wave-uniform
+        const uint32_t at = e - (uint32_t)__shfl((int)(incl_c - cnt_c), (int)shard, 64);
+        const uint2 ent = reinterpret_cast<const uint2*>(qlist)[(size_t)shard * qcap + (hv ? qcap - 1u - at : at)];      // wave-uniform
         const uint32_t hm = ent.y & 0xffffu, nh = (uint32_t)__popc(hm);
         if (g * 8u >= nh) continue;                                          // at most 8 hit pixels in this quadrant: no second group
         const uint32_t tile_index = ent.x >> 2, q = ent.x & 3u;
@@ -454,22 +474,26 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
         if (valid) sd = mk(p.lights[l * 3], p.lights[l * 3 + 1], p.lights[l * 3 + 2]) - so;      // :325
         if (COUNT) diag[4]++;
         const unsigned long long w0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull, st0 = diag[0];
-        const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, win_all[wave], nbase, tbase, n_node, n_tri, diag)
-                                      : packet_any_hit<COUNT, FILTER, PF>(s, valid, so, sd, self, n_node, n_tri, diag);
+        uint32_t steps;
+        const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, steps, win_all[wave], nbase, tbase, n_node, n_tri, diag)
+                                      : packet_any_hit<COUNT, FILTER, PF>(s, valid, so, sd, self, steps, n_node, n_tri, diag);
+        if (p.heavy_steps && steps >= p.heavy_steps && lane == 0) atomicMax(cost_map + ent.x, steps);      // for the next frame's list (srt_kernels.h)
         const unsigned long long sm = __ballot(shadowed);
         if (valid && lg == 0) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)(sm >> (pr * 8u));
         if (COUNT) {
-            const unsigned long long w = __builtin_amdgcn_s_memrealtime() - w0, st = diag[0] - st0;
+            const unsigned long long w = __builtin_amdgcn_s_memrealtime() - w0, st = COUNT ? diag[0] - st0 : 0ull;
             if (w > w_max) w_max = w;
-            if (st > w_max_steps) w_max_steps = st;
-            if (st > 256) { w_long++; w_long_ticks += w; }
+            if (COUNT && st > w_max_steps) w_max_steps = st;
+            if (COUNT && st > 256) { w_long++; w_long_ticks += w; }
+            w_slow += w >= 10000ull;
         }
     }
-    if (COUNT && lane == 0) {      // slots 9..15 and 17..19 are free between the hit shards
+    if (TIMING && lane == 0) {      // slots 9..15 and 17..19 are free between the hit shards
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         atomicAdd(counters + 9, t_end - t_begin); atomicMax(counters + 10, t_end); atomicMax(counters + 11, (1ull << 62) - t_begin);
         atomicMax(counters + 12, w_max); atomicMax(counters + 13, w_max_steps); atomicAdd(counters + 14, w_long); atomicAdd(counters + 15, w_long_ticks);
         atomicAdd(counters + 17, 1ull);
+        atomicAdd(counters + 18, (unsigned long long)w_slow);
     }
     if (COUNT) {
         wave_add(counters + 3, n_node); wave_add(counters + 4, n_tri);
@@ -484,7 +508,9 @@ __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, 
                                                    unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
     shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR, PF>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
 }
-// the frames of a batch (srt_render_device_batch): blockIdx.y = frame, gridDim.x waves-of-four pull the units of THAT frame's list
+// the frames of a batch (srt_render_device_batch): blockIdx.y = frame, gridDim.x waves-of-four pull the units of THAT frame's list.
+// (Waves going on to the next frame's list when theirs is empty: measured twice, 25-35 % SLOWER -- 8,192 waves arriving at a drained
+// frame's 64 fetch counters are tens of thousands of same-address atomics, which the L2 serialises.)
 template <bool FILTER>
 __global__ __launch_bounds__(256, 8) void k_shadow_pk_batch(const FrameTab tab) {
     const FrameItem& it = tab.it[blockIdx.y];
