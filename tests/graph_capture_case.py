@@ -18,7 +18,7 @@ def main():
     W, H, B = 192, 108, 6
     first = lib.DeviceScene(g.flat)
     handles = [first] + [first.share() for _ in range(B - 1)]
-    for L in (2, 9):                                           # the fused pipeline and the 8+-sample pipeline
+    for L in (2, 17):                                          # the fused pipeline and the 16+-sample pipeline (packet shadow kernel, batched)
         params = []
         for f in range(B):
             light = g.light.copy(); light[0] += 30.0 * f

@@ -207,7 +207,7 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
     bad = abi.make_params(W, H, abi.light_staircase(ga.light, 1)); bad.spp = 3
     with pytest.raises(srt.SrtError):
         srt.FrameBatch(handles[:2], [frames[0][1], bad]).render()
-    # more distinct batches than a handle remembers argument tables for (128): the oldest are dropped, results stay right
+    # many distinct batches in a row (rounds 1-2 kept their argument tables in device memory, 128 of them; they travel by value now)
     for k in range(132):
         light = ga.light.copy(); light[1] -= 2.0 * k
         pk = abi.make_params(W, H, abi.light_staircase(light, 2))
@@ -229,6 +229,17 @@ def test_frames_of_a_step_in_shared_launches_are_the_single_renders(srt):
     del bufs
     for ptr in pinned:
         L_.srt_host_free(ptr)
+
+
+@pytest.mark.parametrize("heavy_steps", ["2", "9", "0"])
+def test_heavy_quadrant_lists_change_order_only(heavy_steps):
+    """The packet shadow kernel deals quadrants whose walks were long in the previous call first (batch calls; srt_kernels.h).  With the
+    threshold at 2 and 9 steps nearly every / a good part of the quadrants are heavy ones from the second call on: frames stay the single
+    renders bit for bit (tests/heavy_list_case.py, own process: the library reads SRT_HEAVY_STEPS once)."""
+    import subprocess, sys, os
+    env = dict(os.environ, SRT_HEAVY_STEPS=heavy_steps)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "heavy_list_case.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "heavy list case: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("L", [1, 9])
