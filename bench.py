@@ -153,14 +153,14 @@ def measure(args):
     # frame's shading -- a short, latency-bound launch -- overlaps the next frame's tracing.  K3, N = 1: 0.147 ms per frame on one
     # stream, 0.137 on two, 0.135 on four.
     S = max(1, min(args.streams if args.streams > 0 else 4, B))
-    # A rank that owns an EIGHTH of every frame (or less) issues the frames of a step through srt_render_device_batch (fused
-    # pipeline, 1..7 light samples): one pair of launches for all of them, which fills the chip where such a share does not
-    # (0.0203 ms per share against 0.0256 frame by frame on 4 streams).  Bigger shares fill it well enough, and frame by
-    # frame their shading overlaps the next trace (a half: 0.0707 against 0.0768 batched; whole frames 0.135 against 0.149).
+    # A rank that owns a QUARTER of every frame (or less) issues the frames of a step through srt_render_device_batch: one pair of
+    # launches for all of them, which fills the chip where such a share does not (round 3, frame tables by value: a quarter 1.187 ms
+    # per 36-frame step against 1.256 frame by frame on 4 streams, an eighth 0.635; a half 2.281 against 2.282 and whole frames 4.33
+    # against 4.28: bigger shares fill the chip well enough, and frame by frame their shading overlaps the next trace).
     # One handle per frame of a batch, else one per stream.
     split_n = int(args.emulate_split.split("/")[1]) if args.emulate_split else world // max(1, args.frame_groups)
     n_mine = B // max(1, args.frame_groups)
-    batch = (args.batch == "on" or (args.batch == "auto" and split_n > 4)) and L >= 1 and args.variant == 0 and args.spp == 1 and n_mine > 1
+    batch = (args.batch == "on" or (args.batch == "auto" and split_n >= 4)) and L >= 1 and args.variant == 0 and args.spp == 1 and n_mine > 1
     scenes_ = [lib.DeviceScene(g.flat, device=local_rank)]
     scenes_ += [scenes_[0].share() for _ in range((max(S, n_mine) if batch else S) - 1)]      # the frames of a step render ONE scene: one copy of its records
     scene = scenes_[0]

@@ -904,13 +904,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
-    // packet shadow walks of this many node steps put their quadrant on the heavy list of the next frame (srt_kernels.h).  Only for frames
-    // of a BATCH call: there the frames' shadow rays are one launch and its tail is idle machine (a K4 step of eight share-frames 2.24 ->
-    // 1.73 ms).  Frames launched one by one on several streams pipeline -- the next frame's closest-hit launch fills the slots a tail
-    // frees -- and lose that when the launch ends abruptly (K4 on four streams 10.1 -> 10.5-11.1 ms per 8 frames, K3 with 16 samples
-    // 3.38 -> 3.6-4.0; one stream: no difference), so they keep the plain order.  SRT_HEAVY_STEPS overrides (0 = off).
-    static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
-    dp.heavy_steps = (bc && variant != 59) ? heavy_default : 0u;
+    dp.heavy_steps = 0u;                                   // (set for the frames a batch call holds back, below)
     if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 59)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
@@ -1039,6 +1033,13 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // 8+ light samples, held back: node-queue closest hit, packet shadow kernel and shading of the batch's frames in three launches
                 FrameItem it{s->dev, fp, o_hit, o_t, o_lin, o_rgb8, s->ws_shadow, ctr, zero_next, s->d_qcount, s->ws_qlist, s->qcap, 0u};
                 it.p.shadow_px_major = 1u;
+                // packet shadow walks of this many node steps put their quadrant on the heavy list of the next frame (srt_kernels.h).  Only
+                // for the frames of a batch: their shadow rays are ONE launch and its tail is idle machine (a K4 step of eight share-frames
+                // 2.24 -> 1.73 ms).  Frames launched one by one on several streams pipeline -- the next frame's closest-hit launch fills the
+                // slots a tail frees -- and lose that when the launch ends abruptly (K4 on four streams 10.1 -> 10.5-11.1 ms per 8 frames,
+                // K3 with 16 samples 3.38 -> 3.6-4.0; one stream: no difference): k_shadow_pk is built without the heavy lists.
+                static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
+                it.p.heavy_steps = heavy_default;
                 bc->items_pk.push_back(it);
                 if (p->n_lights > bc->max_lights) bc->max_lights = p->n_lights;
                 std::snprintf(s->pipeline, sizeof(s->pipeline), "k_closest_hit_nq+k_shadow_pk+k_shade_tile (batched)");

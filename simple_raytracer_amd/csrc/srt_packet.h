@@ -52,7 +52,7 @@ __device__ __forceinline__ bool packet_slab(V3 o, V3 d, RayRcp rc, const DevNode
 // an inner node and the first triangle of a leaf (PF >= 2) are requested at the TOP of the step, while the slab test of node i runs,
 // and the next triangle of a leaf while the current one is tested.  Same visits, same tests, same order: only loads that may turn out
 // unused (clamped into the arrays).
-template <bool COUNT, bool FILTER, int PF = 0>
+template <bool COUNT, bool FILTER, int PF = 0, bool STEPS = false>
 __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3 ro, V3 rd, int2 self, uint32_t& steps,
                                                unsigned long long& n_node, unsigned long long& n_tri, unsigned long long* diag = nullptr) {
     steps = 0u;                                              // node steps of this walk (wave-uniform): what makes a quadrant a heavy one
@@ -76,7 +76,7 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
 #define SRT_ARRIVED(a, b) asm("" : "+s"((a).x), "+s"((a).y), "+s"((a).z), "+s"((a).w), "+s"((b).x), "+s"((b).y), "+s"((b).z), "+s"((b).w))
         SRT_ARRIVED(na, nb);
         while (i < N) {
-            steps++;
+            if (STEPS) steps++;
             const uint32_t i1 = i < last ? i + 1u : last;
             const int32_t skip = __float_as_int(nb.z), leaf = __float_as_int(nb.w);
             const bool is_leaf = leaf >= 0;
@@ -128,7 +128,7 @@ __device__ __forceinline__ bool packet_any_hit(const DevScene& s, bool valid, V3
     }
     while (i < N) {
         const DevNode nd = s.nodes[i];                          // wave-uniform index: one request per wave
-        steps++;
+        if (STEPS) steps++;
         if (COUNT && diag) diag[0]++;
         const bool act = n == i;
         bool pass = false;
@@ -381,7 +381,11 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
 // =================================================================================================
 // qcount: [0, 64) entries per shard list (filled by the closest-hit kernel), [64, 128) units handed out per fetch shard; counters
 // QL_STRIDE words apart.  Both are zeroed by the shading kernel that follows.
-template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR, int PF = 0>
+// HEAVY: the kernel of a batch call -- two lists per shard (heavy quadrants first, srt_kernels.h) and the cost map for the next call.  The
+// single-frame kernel is built without (its closest-hit launch gets heavy_steps = 0 and fills the ordinary lists only): the second
+// prefix sum, the step counter and two more spilled registers cost it 2-6 % (same box: K4 9.7-10.0 -> 10.05-10.1 ms per 8 frames, K3
+// with 16 samples 3.33 -> 3.51-3.61) and its frames pipeline on their streams anyway.
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR, int PF = 0, bool HEAVY = false>
 __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParams& p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
                                                unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
@@ -393,19 +397,20 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const uint32_t n_lc8 = (p.n_lights + 7u) >> 3;                        // chunks of 8 light samples = bytes per pixel
     const uint32_t upe = 2u * n_lc8;                                      // units per entry: two groups of 8 hit ranks x the chunks
     const uint32_t pr = lane >> 3, lg = lane & 7u;                        // this lane's pixel slot and light sample within a walk
-    // prefix sums over the shard list lengths, heavy lists and the others: lane k holds shard k
-    uint32_t cnt = qcount[lane * QL_STRIDE], cnt_h = qcount[(2 * QL_SHARDS + lane) * QL_STRIDE];
+    // prefix sums over the shard list lengths (HEAVY: heavy lists and the others): lane k holds shard k
+    uint32_t cnt = qcount[lane * QL_STRIDE], cnt_h = HEAVY ? qcount[(2 * QL_SHARDS + lane) * QL_STRIDE] : 0u;
     cnt = cnt < qcap ? cnt : qcap; cnt_h = cnt_h < qcap ? cnt_h : qcap;
     uint32_t incl = cnt, incl_h = cnt_h;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64), oh = (uint32_t)__shfl_up((int)incl_h, off, 64);
-        if (lane >= (uint32_t)off) { incl += o; incl_h += oh; }
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= (uint32_t)off) incl += o;
+        if (HEAVY) { const uint32_t oh = (uint32_t)__shfl_up((int)incl_h, off, 64); if (lane >= (uint32_t)off) incl_h += oh; }
     }
-    const uint32_t n_rest = (uint32_t)__shfl((int)incl, 63, 64), n_heavy = (uint32_t)__shfl((int)incl_h, 63, 64);
-    const uint32_t n_units = (n_rest + n_heavy) * upe, units_h = n_heavy * upe;        // the heavy entries' units come first
+    const uint32_t n_rest = (uint32_t)__shfl((int)incl, 63, 64), n_heavy = HEAVY ? (uint32_t)__shfl((int)incl_h, 63, 64) : 0u;
+    const uint32_t n_units = (n_rest + n_heavy) * upe, units_h = n_heavy * upe;
     uint32_t* const cost_map = quadrant_cost_map(const_cast<uint32_t*>(qlist), qcap);
-    const uint32_t every = units_h && n_units / (2u * units_h) > 1u ? n_units / (2u * units_h) : 1u;
+    const uint32_t every = HEAVY && units_h && n_units / (2u * units_h) > 1u ? n_units / (2u * units_h) : 1u;
     uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
@@ -438,9 +443,9 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
         // the launch (all of them first was measured too: a share of a frame gained as much, but whole frames on four streams LOST 7-15 % --
         // a launch that opens with nothing but long latency-bound walks and closes with nothing but short issue-bound ones uses
         // the machine worse than the mix)
-        const uint32_t hslot = u / every;
-        const bool hv = hslot < units_h && hslot * every == u;               // wave-uniform
-        const uint32_t uu = hv ? hslot : u - (hslot < units_h ? hslot + 1u : units_h), n_entries = hv ? n_heavy : n_rest;
+        const uint32_t hslot = HEAVY ? u / every : 0u;
+        const bool hv = HEAVY && hslot < units_h && hslot * every == u;      // wave-uniform
+        const uint32_t uu = !HEAVY ? u : hv ? hslot : u - (hslot < units_h ? hslot + 1u : units_h), n_entries = hv ? n_heavy : n_rest;
         if (ENTRY_MAJOR) { e = uu / upe; const uint32_t w_ = uu - e * upe; lc = w_ >> 1; g = w_ & 1u; }
         else { lc = uu / (2u * n_entries); const uint32_t ue = uu - lc * 2u * n_entries; g = ue / n_entries; e = ue - g * n_entries; }
         const uint32_t incl_c = hv ? incl_h : incl, cnt_c = hv ? cnt_h : cnt;
@@ -476,8 +481,8 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
         const unsigned long long w0 = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull, st0 = diag[0];
         uint32_t steps;
         const bool shadowed = WINDOWS ? packet_any_hit_win<COUNT, FILTER>(s, valid, so, sd, self, steps, win_all[wave], nbase, tbase, n_node, n_tri, diag)
-                                      : packet_any_hit<COUNT, FILTER, PF>(s, valid, so, sd, self, steps, n_node, n_tri, diag);
-        if (p.heavy_steps && steps >= p.heavy_steps && lane == 0) atomicMax(cost_map + ent.x, steps);      // for the next frame's list (srt_kernels.h)
+                                      : packet_any_hit<COUNT, FILTER, PF, HEAVY>(s, valid, so, sd, self, steps, n_node, n_tri, diag);
+        if (HEAVY && p.heavy_steps && steps >= p.heavy_steps && lane == 0) atomicMax(cost_map + ent.x, steps);      // for the next frame's list (srt_kernels.h)
         const unsigned long long sm = __ballot(shadowed);
         if (valid && lg == 0) reinterpret_cast<uint8_t*>(shadow_px)[(size_t)pix * n_lch * 8u + lc] = (uint8_t)(sm >> (pr * 8u));
         if (COUNT) {
@@ -514,5 +519,5 @@ __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, 
 template <bool FILTER>
 __global__ __launch_bounds__(256, 8) void k_shadow_pk_batch(const FrameTab tab) {
     const FrameItem& it = tab.it[blockIdx.y];
-    shadow_pk_body<false, FILTER, false, false>(it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
+    shadow_pk_body<false, FILTER, false, false, 0, true>(it.s, it.p, it.hit_id, it.t_out, it.qcount, it.qlist, it.qcap, it.shadow_bits, it.counters);
 }
