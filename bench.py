@@ -312,10 +312,18 @@ def measure(args):
                          world, dev, args.backend) if world > 1 else None
     # N > 1: what rank 0 holds after the last gather must be the frame one GPU renders (every step renders the same frames)
     gathered_ok = None
+    gathered_parity = None
     if world > 1 and rank == 0 and FG == 1 and gather.frame is not None:
         whole = lib.DeviceScene(g.flat, device=local_rank).render(abi.make_params(W, H, lights, spp=args.spp), want=("rgb8",))["rgb8"]
         got = gather.frame.cpu().numpy()
         gathered_ok = bool(all(np.array_equal(got[f], whole) for f in (0, got.shape[0] - 1)))
+        # and against the compiled reference's own frame where the golden holds this size: only the 8-bit framebuffer travels, so that
+        # is what can be compared at N > 1 (hit ids / t / linear colour of the same kernels are in the N = 1 line's parity block)
+        ref8 = g.out(W, H, L, "rgb8") if hasattr(g, "out") and args.spp == 1 and g.out(W, H, L, "hit_id") is not None else None
+        if ref8 is not None:
+            d8 = np.abs(got[0].astype(np.int32) - ref8.astype(np.int32))
+            gathered_parity = {"against": f"tests/golden/scene_{g.name}.npz (rgb8 of the compiled reference, {W}x{H}, {L} light sample(s)); frame 0 as rank 0 assembled it",
+                               "rgb8_pixels_differing": int((d8.max(-1) > 0).sum()), "rgb8_max_LSB": int(d8.max()), "pixels": int(W * H)}
     # per-kernel durations: HIP events on the launch stream over B eager renders of the same frames (the events of
     # a captured graph cannot be read back), averaged by srt_sync
     for sc_ in scenes_:
@@ -411,6 +419,7 @@ def measure(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             **({"backend": "gloo (rehearsal, not a measurement of the RCCL path)"} if args.backend == "gloo" and world > 1 else {}),
             **({"gathered_frames_equal_one_gpu_render": gathered_ok} if gathered_ok is not None else {}),
+            **({"parity": gathered_parity} if gathered_parity is not None else {}),
             **(phases if phases is not None else {}),
             "config": {"workload": f"{args.workload}: stanford-bunny (69,451 tris) over a ground slab, BVH + slab-AABB, "
                                    f"{W}x{H}, {L} light sample(s) [BASELINE.json configs[2]]" if args.workload == "ground_bunny"
