@@ -1186,7 +1186,8 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         const uint64_t wgs_all = (uint64_t)scenes[0]->n_cu * 8;         // the chip's worth of waves, shared by the frames
         uint32_t wgs = (uint32_t)((wgs_all + held_pk - 1) / held_pk);
         if ((uint64_t)wgs > max_units / 4 + 1) wgs = (uint32_t)(max_units / 4 + 1);
-        hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true>), g8, block, 0, stream, tab);
+        // grid = (tiles per row, frames, tile rows): the same tile row of all the frames is in flight together (srt_kernels.h)
+        hipLaunchKernelGGL((k_closest_hit_nq_batch<512, true, true>), dim3(g8.x, held_pk, g8.y), block, 0, stream, tab);
         hipLaunchKernelGGL((k_shadow_pk_batch<true>), dim3(wgs, held_pk), block, 0, stream, tab);
         if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g16, block, 0, stream, tab);
         else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g16, block, 0, stream, tab);
@@ -1198,7 +1199,7 @@ static int render_device_batch_impl(uint32_t n, srt_scene* const* scenes, const 
         std::memset(&tab, 0, sizeof(tab));
         std::memcpy(tab.it, bc.items.data() + first, held * sizeof(FrameItem));
         const dim3 g_trace((bc.wl + 7) / 8, (bc.rows + 7) / 8, held), g_shade((bc.wl + 15) / 16, (bc.rows + 15) / 16, held);
-        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 7, 16>), g_trace, block, 0, stream, tab);
+        hipLaunchKernelGGL((k_trace_nq_batch<512, true, 7, 16, true>), dim3(g_trace.x, held, g_trace.y), block, 0, stream, tab);
         if (batch_int_shin) hipLaunchKernelGGL(k_shade_tile_batch<1>, g_shade, block, 0, stream, tab);
         else                hipLaunchKernelGGL(k_shade_tile_batch<0>, g_shade, block, 0, stream, tab);
         if (hipGetLastError() != hipSuccess) rc = SRT_ERR_DEVICE;

@@ -1529,7 +1529,7 @@ __device__ __forceinline__ void shade_hit_pixel(const DevScene& s, const DevPara
 // WIDE (the 64 B inner-node records): measured per kernel -- the stand-alone shadow kernel, whose rays cross a
 // soup's overlapping boxes hundreds of nodes deep, gains 10 % from it; the fused kernel and the closest-hit kernel, whose frames are
 // mostly short waves, lose 5 % (16 VGPRs of record per lane instead of 8: spills at six waves per SIMD), so they keep the 32 B records.
-template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false, bool WIDE = false>
+template <bool COUNT, int NQCAP, bool FILTER, int RS, bool XCD_ROWS, bool ROOTS_AGAIN, bool SHADE = false, bool CAM = false, bool WIDE = false, bool ROW_Z = false>
 __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams& p, int32_t* __restrict__ hit_id, float* __restrict__ t_out,
                                               float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
                                               unsigned long long* __restrict__ shadow_bits, unsigned long long* __restrict__ counters,
@@ -1557,7 +1557,7 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     // read the same nodes and triangles, hit in the same L2: 1 M-triangle soup -15 %.  For a scene of a few MB the plain
     // order is as good or slightly better (K3: +1 % with the row deal, +2 % with a run-time switch), so it has its own build.
     const uint32_t gx = gridDim.x;
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    uint32_t bx = blockIdx.x, by = ROW_Z ? blockIdx.z : blockIdx.y;      // ROW_Z: a batch launched with the tile row in z and the frame in y
     if (XCD_ROWS) {
         const uint32_t w = blockIdx.y * gx + blockIdx.x, idx = w >> 3;
         by = (idx / gx) * 8u + (w & 7u); bx = idx % gx;
@@ -1639,9 +1639,15 @@ constexpr uint32_t FRAME_TAB_MAX = 40;
 struct FrameTab { FrameItem it[FRAME_TAB_MAX]; };
 static_assert(sizeof(FrameTab) <= 16384, "the frame table is copied into the kernel-argument segment at every launch");
 // the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)
-template <int NQCAP, bool FILTER>
+// ROW_Z: grid (tiles per row, frames, tile rows) instead of (tiles per row, tile rows, frames): workgroups are dispatched x, then y, then
+// z, so the SAME tile row of all the batch's frames is in flight together -- frames of one scene read the same records there, where a
+// share's consecutive tile rows (64 image rows apart at N = 8) read different ones.  Same box, shares of 8: K4 2.03 -> 1.86 ms per step,
+// K3 0.625 -> 0.599, a quarter of K3 1.179 -> 1.128.  (The bench's frames of a step are one picture, which flatters this; the frames of
+// an orbit are 10 degrees apart and still look at the same part of the scene in the same rows.)  Shipped as the only order.
+template <int NQCAP, bool FILTER, bool ROW_Z = false>
 __global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameTab tab) {
-    const FrameItem& it = tab.it[blockIdx.z];
+    const FrameItem& it = tab.it[ROW_Z ? blockIdx.y : blockIdx.z];
+    const uint32_t tile_row = ROW_Z ? blockIdx.z : blockIdx.y;
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ unsigned long long best_all[4][NQ_P];
@@ -1650,16 +1656,16 @@ __global__ __launch_bounds__(256, 7) void k_closest_hit_nq_batch(const FrameTab 
     const uint32_t wave = threadIdx.x >> 6;
     int32_t id; float t; V3 d;
     const bool roots_done = it.s.n_objects <= 32u;
-    if (finish_background_tile<FILTER>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, nullptr, blockIdx.x, blockIdx.y, gridDim.x, root_pass)) return;
+    if (finish_background_tile<FILTER>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, nullptr, blockIdx.x, tile_row, gridDim.x, root_pass)) return;
     closest_hit_phase<false, NQCAP, 2, 2, FILTER, false, false>(it.s, it.p, nq_all[wave], tq_all[wave], best_all[wave], dir_all[wave],
-                                                  it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, id, t, d, blockIdx.x, blockIdx.y, gridDim.x, wave,
+                                                  it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.counters, id, t, d, blockIdx.x, tile_row, gridDim.x, wave,
                                                   it.qcount, it.qlist, it.qcap, roots_done ? root_pass + wave * 16 : nullptr);
 }
 
-template <int NQCAP, bool FILTER, int MINW, int RS>
+template <int NQCAP, bool FILTER, int MINW, int RS, bool ROW_Z = false>
 __global__ __launch_bounds__(256, MINW) void k_trace_nq_batch(const FrameTab tab) {
-    const FrameItem& it = tab.it[blockIdx.z];
-    trace_nq_body<false, NQCAP, FILTER, RS, false, false>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
+    const FrameItem& it = tab.it[ROW_Z ? blockIdx.y : blockIdx.z];
+    trace_nq_body<false, NQCAP, FILTER, RS, false, false, false, false, false, ROW_Z>(it.s, it.p, it.hit_id, it.t_out, it.rgb_linear, it.rgb8, it.shadow_bits, it.counters);
 }
 
 // =================================================================================================
