@@ -160,7 +160,10 @@ def measure(args):
     # One handle per frame of a batch, else one per stream.
     split_n = int(args.emulate_split.split("/")[1]) if args.emulate_split else world // max(1, args.frame_groups)
     n_mine = B // max(1, args.frame_groups)
-    batch = (args.batch == "on" or (args.batch == "auto" and split_n >= 4)) and L >= 1 and args.variant == 0 and args.spp == 1 and n_mine > 1
+    # (second half of round 3, batch launches with the same tile row of all frames in flight together: the fused pipeline (1..7 samples) is
+    # ahead in batches from a HALF on -- 2.18 against 2.25 ms per step; whole frames 4.33 against 4.30 --, the 16+-sample pipeline from a quarter)
+    batch_from = 2 if 1 <= L <= 7 else 4
+    batch = (args.batch == "on" or (args.batch == "auto" and split_n >= batch_from)) and L >= 1 and args.variant == 0 and args.spp == 1 and n_mine > 1
     scenes_ = [lib.DeviceScene(g.flat, device=local_rank)]
     scenes_ += [scenes_[0].share() for _ in range((max(S, n_mine) if batch else S) - 1)]      # the frames of a step render ONE scene: one copy of its records
     scene = scenes_[0]
