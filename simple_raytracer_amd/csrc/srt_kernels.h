@@ -440,15 +440,19 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
             // one triangle per iteration, the next one's three dwordx4 loads issued before the current test: a wave spends
             // most of its life behind s_waitcnt, and the all-lanes-rejected exits of a single test skip more code than two
             // interleaved tests could (measured: 5 % of the launch); ids rise inside a lane, so strict '<' keeps the first minimum
-            const float4* tp = reinterpret_cast<const float4*>(CAM ? (const void*)s.tris : (const void*)s.tris_o) + ((size_t)first + sub) * 3;
-            float4 n0, n1, n2;
-            if (sub < cnt) { n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
+            // The GENERAL record (P1, e1, e2) also for rays from the origin: 12 operations more a test than the origin record (tvec, qvec
+            // precomputed; still what the packet kernel reads, whose operands are scalar), but ONE record array in the caches instead of two
+            // -- this phase and the shadow phase then read the same 48 bytes of a triangle.  o = 0 gives tvec = 0 - P1 and qvec =
+            // cross(tvec, e1) with the host's operations: same bits.  Same box: K3 4.30 -> 4.25 ms per 36 frames, cube over ground
+            // 3.12 -> 3.06, K4's closest-hit launch 0.239 -> 0.232 ms.
+            const float4* tp = reinterpret_cast<const float4*>(s.tris) + ((size_t)first + sub) * 3;
+            float4 n0, n1; float n2;                     // (the record's last three words are the face normal: not read here)
+            if (sub < cnt) { n0 = tp[0]; n1 = tp[1]; n2 = tp[2].x; }
             for (uint32_t k = sub; k < cnt; k += S) {
-                const float4 a0 = n0, a1 = n1, a2 = n2;
-                if (k + S < cnt) { tp += 3 * S; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }      // the next triangle's record is in flight during this test
+                const float4 a0 = n0, a1 = n1; const float a2 = n2;
+                if (k + S < cnt) { tp += 3 * S; n0 = tp[0]; n1 = tp[1]; n2 = tp[2].x; }      // the next triangle's record is in flight during this test
                 if (COUNT) n_tri++;
-                const float ta = CAM ? ray_triangle(o, d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x))
-                                     : ray_triangle_origin(d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2.x), mk(a2.y, a2.z, a2.w));
+                const float ta = ray_triangle(o, d, mk(a0.x, a0.y, a0.z), mk(a0.w, a1.x, a1.y), mk(a1.z, a1.w, a2));
                 // candidate iff t != -inf && t < best (initially +inf, :408); NaN fails '<'; -0.0 == +0.0 keeps the first
                 if (ta != SRT_NEG_INF && ta < bt) { bt = ta; bi = first + k; }
             }
