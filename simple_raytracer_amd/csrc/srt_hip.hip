@@ -1417,7 +1417,9 @@ int srt_debug_valu_rate(int device, uint32_t iters, double* out) {
     DevBuf sink, st;
     KAT_TRY(sink.alloc((size_t)wgs * 256 * 4)); KAT_TRY(st.alloc((size_t)wgs * 4 * 8 * 8));
     for (int rep = 0; rep < 2; rep++) {                        // the first launch warms the clock
-        hipLaunchKernelGGL(k_valu_rate, dim3(wgs), dim3(256), 0, 0, iters, (float*)sink.p, (unsigned long long*)st.p);
+        static const bool packed = std::getenv("SRT_VALU_PACKED") != nullptr;        // measure v_pk_fma_f32 instead (same instruction count)
+        if (packed) hipLaunchKernelGGL(k_valu_rate<true>, dim3(wgs), dim3(256), 0, 0, iters, (float*)sink.p, (unsigned long long*)st.p);
+        else        hipLaunchKernelGGL(k_valu_rate<false>, dim3(wgs), dim3(256), 0, 0, iters, (float*)sink.p, (unsigned long long*)st.p);
         HIP_TRY(hipGetLastError()); HIP_TRY(hipDeviceSynchronize());
     }
     std::vector<unsigned long long> h((size_t)wgs * 32);

@@ -1844,18 +1844,31 @@ __global__ void k_update_roots(uint32_t n_objects, const int2* __restrict__ obj_
 // first wave's start and its last wave's end is what ONE SIMD issues per cycle -- the yardstick bench.py's roofline prices VALU work
 // against (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction over 2 cycles -> 0.5; measured: 0.45).
 // =================================================================================================
+// PACKED: the same count of v_pk_fma_f32 (two f32 fused multiply-adds per lane and instruction): do they issue at the rate of v_fma_f32?
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_valu_rate(uint32_t iters, float* __restrict__ sink, unsigned long long* __restrict__ stamps) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
     float a[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = (float)(threadIdx.x + k) * 1.0e-3f;
     const float b = 0.99999f, c = 1.0e-7f;
+    v2f pa[16]; const v2f pb = { b, b }, pc = { c, c };
+#pragma unroll
+    for (int k = 0; k < 16; k++) pa[k] = v2f{ a[k], a[k] + 1.0f };
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     for (uint32_t i = 0; i < iters; i++) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            for (int k = 0; k < 16; k++) {
+                if (PACKED) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[k]) : "v"(pb), "v"(pc));
+                else        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+            }
+    }
+    if (PACKED) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = pa[k].x + pa[k].y;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
