@@ -178,7 +178,7 @@ def measure(args):
     B_total, B = B, B // FG                      # B: frames THIS rank renders per step
     split_rank, split_world = (emu if emu else (rank % per_group, per_group))
     BC = args.block_cols if split_world > 1 else 0
-    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=args.variant << 8, spp=args.spp)
+    p = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=(args.variant << 8) | (abi.SRT_FLAG_FRAMES_IN_FLIGHT if S > 1 else 0), spp=args.spp)
     rows, Wl = scene.rows(p), scene.cols(p)
     dev = torch.device("cuda", local_rank)
     NB = len(scenes_)
@@ -257,7 +257,8 @@ def measure(args):
     # (torch.cuda.CUDAGraph = HIP stream capture; the launches go through the C ABI on the capturing stream).
     graphs = None
     if not args.no_graph:        # (an odd number of renders per handle leaves the hit counters of replayed frames un-zeroed: only statistics nobody reads)
-        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING, spp=args.spp)
+        p_quiet = tiling.split_params(W, H, lights, split_rank, split_world, BLOCK_ROWS, BC, spp=args.spp,
+                                      flags=(args.variant << 8) | abi.SRT_FLAG_NO_TIMING | (abi.SRT_FLAG_FRAMES_IN_FLIGHT if S > 1 else 0))      # the frames of a step are in flight on S streams
         try:
             render_frames(p_quiet); torch.cuda.synchronize()          # allocate every workspace before capturing
             graphs = []

@@ -89,8 +89,14 @@ enum {
                                          * srt_scene_desc.tri_normals.  The function is pinned by a reference KAT,
                                          * the images only by the oracle (the reference cannot render this mode) */
     SRT_FLAG_COUNT_WORK     = 1u << 1,  /* run the counting build: fills node/tri test counters      */
-    SRT_FLAG_NO_TIMING      = 1u << 2   /* record no HIP events: for launches captured into a hipGraph (an even number
+    SRT_FLAG_NO_TIMING      = 1u << 2,  /* record no HIP events: for launches captured into a hipGraph (an even number
                                          * of renders per graph keeps the two alternating counter sets in step)     */
+    SRT_FLAG_FRAMES_IN_FLIGHT = 1u << 3 /* a HINT, results do not depend on it: this frame is one of several the caller keeps in
+                                         * flight on the device (other streams, other handles).  Launches of a fixed number of
+                                         * waves that pull work (the shadow rays of 16+ light samples) then keep only as many waves
+                                         * as the frame's work can feed and leave the rest of the machine to the other frames; a
+                                         * frame that has the device to itself wants every wave (1080p, 16 samples: 12-16 % faster
+                                         * with the hint on four streams, 11-23 % slower with it on one)                  */
 };
 
 typedef struct srt_params {
@@ -238,7 +244,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
  * size share the launches -- those with 1..7 light samples one pair of launches, those with 8 and more three -- which fills the
  * chip where one frame, or the eighth of it one of eight GPUs owns, does not (a silhouette tile occupies its workgroup for the
  * better part of such a launch); any other frame is launched on its own as srt_render_device would.  The frames' arguments travel
- * by value with the launches (up to 40 frames a launch, more frames = more launches): nothing is allocated or copied, and the call
+ * by value with the launches (up to 36 frames a launch, more frames = more launches): nothing is allocated or copied, and the call
  * may be captured into a hipGraph like any other (ABI version 3; earlier versions kept argument tables in device memory and could not
  * make one while capturing).  Frames with 16 and more light samples: the shadow-ray launch of a call remembers which 4x4-pixel
  * quadrants had long walks and the next call on the same handles deals those early -- order only, results do not depend on it

@@ -15,6 +15,7 @@ SRT_ERR_ARG, SRT_ERR_LAYOUT, SRT_ERR_DEVICE, SRT_ERR_NO_GPU, SRT_ERR_TEXTURE, SR
 SRT_FLAG_SMOOTH_NORMALS = 1 << 0
 SRT_FLAG_COUNT_WORK = 1 << 1
 SRT_FLAG_NO_TIMING = 1 << 2
+SRT_FLAG_FRAMES_IN_FLIGHT = 1 << 3      # hint: other frames are in flight on the device (srt.h)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -905,6 +905,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.heavy_steps = 0u;                                   // (set for the frames a batch call holds back, below)
+    static const uint32_t pk_units_default = [] { const char* e = std::getenv("SRT_PK_UNITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
+    dp.pk_units = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) ? pk_units_default : 0u; dp.pad3_ = 0u;
     if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 59)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
@@ -1040,6 +1042,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // K3 with 16 samples 3.38 -> 3.6-4.0; one stream: no difference): k_shadow_pk is built without the heavy lists.
                 static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
                 it.p.heavy_steps = heavy_default;
+                it.p.pk_units = 0u;                   // the frames of a batch share the machine: every frame keeps its part of the grid (K3 with 16 samples, an eighth: 0.45 ms per step against 0.68 with surplus waves leaving)
                 bc->items_pk.push_back(it);
                 if (p->n_lights > bc->max_lights) bc->max_lights = p->n_lights;
                 std::snprintf(s->pipeline, sizeof(s->pipeline), "k_closest_hit_nq+k_shadow_pk+k_shade_tile (batched)");
@@ -1068,7 +1071,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (pk_shadow) {
             // a fixed number of waves pull units (the shadow rays of 64 / n_lights pixels) from the quadrant list: no grid over the image
             const uint64_t max_units = (uint64_t)n_tiles * 4u * 2u * ((p->n_lights + 7) / 8);
-            const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * 8 ? max_units / 4 + 1 : (uint64_t)s->n_cu * 8);
+            static const uint32_t per_cu = [] { const char* e = std::getenv("SRT_PK_WGS_PER_CU"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 8u; }();
+            const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * per_cu ? max_units / 4 + 1 : (uint64_t)s->n_cu * per_cu);
             if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
             else if ((p->flags >> 8 & 0xffu) == 55)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // record of i + 1 requested ahead (A/B)

@@ -56,8 +56,9 @@ struct DevParams {
     uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
     float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
     uint32_t exp, heavy_steps;    // heavy_steps: packet shadow walks of that many steps make their quadrant a HEAVY one in the next frame's list (0 = off).  exp: experiment switches (A/B variants, wave-uniform branches): bit 0 = queue pushes in LANE order (the round-2 form) instead of node-major
+    uint32_t pk_units, pad3_;     // packet shadow kernel: units a wave should have to walk; surplus waves of the fixed-size grid leave at once (0 = all stay)
 };
-static_assert(sizeof(DevParams) == 152, "DevParams has no implicit padding");
+static_assert(sizeof(DevParams) == 160, "DevParams has no implicit padding");
 
 // counters[0] hit pixels, [1]/[2] node/triangle tests of the closest-hit kernel, [3]/[4] of the shade kernel
 __device__ __forceinline__ void wave_add(unsigned long long* ctr, unsigned long long v) {
@@ -1637,9 +1638,9 @@ static_assert(sizeof(FrameItem) == sizeof(DevScene) + sizeof(DevParams) + 9 * 8 
 // against 0.219, shading 0.135 against 0.122.  Pointer members of a by-value kernel argument are global pointers to the compiler
 // (also behind a dynamic index), nothing has to be allocated, copied or kept alive for a captured graph.  The segment is ordinary
 // memory on this stack (a 26 KB argument was launched and read back on the MI355X; there is no 4 KB ceiling as on other runtimes):
-// 40 frames = 16 KB a launch, a batch of more is issued as several launches -- and every launch boundary costs: the 36 share-frames of a
+// 36 frames (the reference's orbit) = 15 KB a launch, a batch of more is issued as several launches -- and every launch boundary costs: the 36 share-frames of a
 // K3 step at N = 8 in five launches of 8 took 0.81 ms a step, in one launch 0.64.
-constexpr uint32_t FRAME_TAB_MAX = 40;
+constexpr uint32_t FRAME_TAB_MAX = 36;
 struct FrameTab { FrameItem it[FRAME_TAB_MAX]; };
 static_assert(sizeof(FrameTab) <= 16384, "the frame table is copied into the kernel-argument segment at every launch");
 // the unfused closest-hit launch of the 8+-sample pipeline over the frames of a batch (k_closest_hit_nq<false, NQCAP, 2, 2, FILTER>)

@@ -414,6 +414,14 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
+    // The grid is sized for the worst case (every tile full of hits); a frame with few units keeps only as many waves as have ~p.pk_units
+    // units each to walk (at least one per fetch shard): the others leave before their first atomic.  8,192 waves on the 222 k units of a
+    // 1080p frame with 16 samples are 27 units a wave, most of whose life is start-up and contention on the 64 fetch counters -- K3 with
+    // 16 samples 3.40 -> 2.9 ms per 8 frames with the grid cut by hand, K4 (61 units a wave) best with the full grid.
+    if (!COUNT && p.pk_units) {
+        const uint32_t keep = n_units / p.pk_units > (uint32_t)QL_SHARDS ? n_units / p.pk_units : (uint32_t)QL_SHARDS;
+        if (blockIdx.x * 4u + wave >= keep) return;
+    }
     uint32_t home = (blockIdx.x * 4u + wave) & (QL_SHARDS - 1);
     uint32_t k_next = 0;
     // counting build: when this wave started, and what its longest walk was (10 ns ticks of the constant clock)

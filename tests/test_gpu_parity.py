@@ -795,6 +795,9 @@ def test_packet_shadow_walk_with_records_requested_ahead(srt, oracle, name, W, H
         for variant in (55, 56, 57):
             assert np.array_equal(bits(outs[variant]["rgb_linear"]), bits(outs[0]["rgb_linear"])), variant
             assert np.array_equal(outs[variant]["rgb8"], outs[0]["rgb8"]), variant
+        # SRT_FLAG_FRAMES_IN_FLIGHT is a hint (surplus waves of the fixed-size grid leave at once): the same frame
+        h = ds.render(g.params(W, H, L, flags=abi.SRT_FLAG_FRAMES_IN_FLIGHT, **kw))
+        assert np.array_equal(h["hit_id"], outs[0]["hit_id"]) and np.array_equal(bits(h["rgb_linear"]), bits(outs[0]["rgb_linear"])) and np.array_equal(h["rgb8"], outs[0]["rgb8"])
         fin = np.isfinite(c["rgb_linear"]).all(-1)
         assert float(np.abs(outs[0]["rgb_linear"][fin] - c["rgb_linear"][fin]).max()) < 1e-4
 
