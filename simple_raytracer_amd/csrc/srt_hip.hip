@@ -906,7 +906,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.heavy_steps = 0u;                                   // (set for the frames a batch call holds back, below)
     static const uint32_t pk_units_default = [] { const char* e = std::getenv("SRT_PK_UNITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
-    dp.pk_units = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) ? pk_units_default : 0u; dp.pad3_ = 0u;
+    static const uint32_t pk_take_default = [] { const char* e = std::getenv("SRT_PK_TAKE"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 4u; }();
+    const bool in_flight = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) != 0;
+    dp.pk_units = in_flight ? pk_units_default : 0u; dp.pk_take = in_flight && pk_take_default ? pk_take_default : 1u;      // (batch frames: set where they are held back)
     if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 59)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
@@ -1042,6 +1044,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // K3 with 16 samples 3.38 -> 3.6-4.0; one stream: no difference): k_shadow_pk is built without the heavy lists.
                 static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
                 it.p.heavy_steps = heavy_default;
+                it.p.pk_take = pk_take_default ? pk_take_default : 1u;      // unit numbers four at a time: fewer same-address atomics (srt_packet.h)
                 it.p.pk_units = 0u;                   // the frames of a batch share the machine: every frame keeps its part of the grid (K3 with 16 samples, an eighth: 0.45 ms per step against 0.68 with surplus waves leaving)
                 bc->items_pk.push_back(it);
                 if (p->n_lights > bc->max_lights) bc->max_lights = p->n_lights;

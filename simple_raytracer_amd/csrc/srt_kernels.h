@@ -56,7 +56,7 @@ struct DevParams {
     uint32_t cam;                 // camera mode (srt_params.ray_matrix, an extension): rays are taken into the scene's space
     float cm[12];                 // columns 0..2 (direction) and 3 (origin) of that matrix, xyz each
     uint32_t exp, heavy_steps;    // heavy_steps: packet shadow walks of that many steps make their quadrant a HEAVY one in the next frame's list (0 = off).  exp: experiment switches (A/B variants, wave-uniform branches): bit 0 = queue pushes in LANE order (the round-2 form) instead of node-major
-    uint32_t pk_units, pad3_;     // packet shadow kernel: units a wave should have to walk; surplus waves of the fixed-size grid leave at once (0 = all stay)
+    uint32_t pk_units, pk_take;   // packet shadow kernel: units a wave should have to walk -- surplus waves of the fixed-size grid leave at once (0 = all stay) --, and how many unit numbers one atomic takes
 };
 static_assert(sizeof(DevParams) == 160, "DevParams has no implicit padding");
 

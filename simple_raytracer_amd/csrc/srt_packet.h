@@ -410,7 +410,8 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const uint32_t n_rest = (uint32_t)__shfl((int)incl, 63, 64), n_heavy = HEAVY ? (uint32_t)__shfl((int)incl_h, 63, 64) : 0u;
     const uint32_t n_units = (n_rest + n_heavy) * upe, units_h = n_heavy * upe;
     uint32_t* const cost_map = quadrant_cost_map(const_cast<uint32_t*>(qlist), qcap);
-    const uint32_t every = HEAVY && units_h && n_units / (2u * units_h) > 1u ? n_units / (2u * units_h) : 1u;
+    // (odd: unit u is fetched through shard u % 64, and an even spacing would put every heavy unit into a few of the 64 shards)
+    const uint32_t every = HEAVY && units_h && n_units / (2u * units_h) > 1u ? (n_units / (2u * units_h)) | 1u : 1u;
     uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
@@ -429,21 +430,31 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long w_max = 0, w_max_steps = 0, w_long = 0, w_long_ticks = 0;
     uint32_t w_slow = 0;                                          // walks of 100 us and more
-    if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
+    // units are taken `take` at a time (p.pk_take, >= 1): one atomic per `take` walks on the 64 fetch counters that every wave of the launch hits
+    // -- 8,192 waves on 64 addresses are same-address atomics the L2 serialises: K3 with 64 samples 9.19 -> 7.41 ms per 8 frames with four
+    // at a time, K4 10.05 -> 9.36, an eighth of K4 1.93 -> 1.69.  A frame alone on the device loses with it where walks are long (K4 on
+    // one stream 11.8 -> 12.4: a wave that holds a long walk holds three more units back), so the host asks for four only when other
+    // frames are in flight (the hint, batch calls); one at a time near the end of a shard was tried on top and changed nothing for it.
+    const uint32_t take = p.pk_take ? p.pk_take : 1u;
+    uint32_t kc = 0, ke = 0;                                  // the numbers in hand: [kc, ke) of shard `home`
+    if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, take);
     for (;;) {
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
-        const uint32_t u = k * QL_SHARDS + home;
+        const bool fresh = kc == ke;
+        if (fresh) { kc = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next); ke = kc + take; }
+        const uint32_t u = kc * QL_SHARDS + home;
         if (u >= n_units) {
+            kc = ke = 0;
             // home shard empty: look (agent-scope loads, the counters only grow) for a shard that still has units, next after home
             const uint32_t seen = __hip_atomic_load(fetch + lane * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long open = __ballot((unsigned long long)seen * QL_SHARDS + lane < (unsigned long long)n_units);
             if (!open) break;
             const unsigned long long rot = home == 63u ? open : ((open >> (home + 1u)) | (open << (63u - home)));      // bit j = shard home + 1 + j
             home = (home + 1u + (uint32_t)__builtin_ctzll(rot)) & (QL_SHARDS - 1);
-            if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);
+            if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, take);
             continue;
         }
-        if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, 1u);        // the next unit's number: in flight during this walk
+        if (fresh && lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, take);        // the next numbers: in flight during these walks
+        kc++;
         // unit -> (chunk of 8 samples, entry, pixel group): consecutive units are different ENTRIES, so that the waves that
         // start together do not all read the same quadrant
         uint32_t lc, g, e;
