@@ -248,7 +248,7 @@ int srt_render_device(srt_scene* s, const srt_params* p, void* stream,
  * may be captured into a hipGraph like any other (ABI version 3; earlier versions kept argument tables in device memory and could not
  * make one while capturing).  Frames with 16 and more light samples: the shadow-ray launch of a call remembers which 4x4-pixel
  * quadrants had long walks and the next call on the same handles deals those early -- order only, results do not depend on it
- * (SRT_HEAVY_STEPS=0 in the environment turns it off).  No per-frame times: srt_sync()'s ms_* keep the values of the last timed
+ * (SRT_HEAVY_STEPS=0 in the environment turns it off; single frames without SRT_FLAG_FRAMES_IN_FLIGHT do the same).  No per-frame times: srt_sync()'s ms_* keep the values of the last timed
  * render of each handle. */
 int srt_render_device_batch(uint32_t n, srt_scene* const* scenes, const srt_params* params, void* stream,
                             int32_t* const* d_hit_id, float* const* d_t, float* const* d_rgb_linear, uint8_t* const* d_rgb8);

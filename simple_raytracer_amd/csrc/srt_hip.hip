@@ -904,7 +904,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
-    dp.heavy_steps = 0u;                                   // (set for the frames a batch call holds back, below)
+    dp.heavy_steps = 0u;                                   // (set below: frames a batch call holds back, and single frames that have the device to themselves)
     static const uint32_t pk_units_default = [] { const char* e = std::getenv("SRT_PK_UNITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
     static const uint32_t pk_take_default = [] { const char* e = std::getenv("SRT_PK_TAKE"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 4u; }();
     const bool in_flight = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) != 0;
@@ -949,8 +949,9 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     }
 
     // One pass of the path over this call's pixels: closest hit (+ shadow rays) and shading.
-    auto launch_frame = [&](const DevParams& fp, int32_t* o_hit, float* o_t, float* o_lin, uint8_t* o_rgb8,
+    auto launch_frame = [&](const DevParams& fp_in, int32_t* o_hit, float* o_t, float* o_lin, uint8_t* o_rgb8,
                             unsigned long long* zero_next, hipEvent_t* ev) -> int {
+        DevParams fp = fp_in;
         if (variant == 1) {                // v0 reference kernels: per-lane walk with inline triangle loop, per-pixel shade
             if (count) hipLaunchKernelGGL(k_closest_hit<true>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, ctr);
             else       hipLaunchKernelGGL(k_closest_hit<false>, grid, block, 0, stream, s->dev, fp, o_hit, o_t, ctr);
@@ -989,6 +990,11 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         const bool few_nodes_mid = variant == 0 && !count && !fp.cam && p->n_lights >= 8 && p->n_lights < 16 && s->rec->overlap < 14.0 && !s->rec->prefer_packet &&
                                    (p->flags >> 8 & 0xffu) == 0;
         const bool pk_shadow = p->n_lights && (variant == 21 || variant == 22 || (variant == 0 && p->n_lights >= 8 && !few_nodes_mid));
+        // A frame that has the device to itself (no in-flight hint, not part of a batch call): quadrants whose walks were long in this
+        // handle's previous frame are dealt early (srt_kernels.h) -- nothing else fills the slots the launch's tail frees.  Same box:
+        // K3 with 16 samples on one stream 4.04 -> 3.70 ms per 8 frames, K4 11.89 -> 11.72; with frames on four streams the lists LOSE
+        // (K4 9.41 -> 9.64, the reference's main() scene 6.55 -> 6.91), so the hint turns them off.
+        if (pk_shadow && variant == 0 && (p->flags >> 8 & 0xffu) == 0 && !count && !in_flight && !bc) fp.heavy_steps = 64u;
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
@@ -1080,6 +1086,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
             else if ((p->flags >> 8 & 0xffu) == 55)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // record of i + 1 requested ahead (A/B)
             else if ((p->flags >> 8 & 0xffu) == 56)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 2>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // + skip[i] / first triangle (A/B)
+            else if (fp.heavy_steps)                  hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 0, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // heavy quadrants dealt early (a frame alone on the device)
             else if ((p->flags >> 8 & 0xffu) == 58)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, -1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // the shipped walk with wave clocks (SRT_DIAG_COUNTERS)
             else if ((p->flags >> 8 & 0xffu) == 57)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 0>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // the plain walk (A/B)
             else if ((p->flags >> 8 & 0xffu) == 25)   hipLaunchKernelGGL((k_shadow_pk<false, true, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // records through LDS windows (A/B)

@@ -526,11 +526,11 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     }
 }
 
-template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false, int PF = 0>
+template <bool COUNT, bool FILTER, bool WINDOWS, bool ENTRY_MAJOR = false, int PF = 0, bool HEAVY = false>
 __global__ __launch_bounds__(256, WINDOWS ? 1 : 8) void k_shadow_pk(DevScene s, DevParams p, const int32_t* __restrict__ hit_id, const float* __restrict__ t_in,
                                                    uint32_t* __restrict__ qcount, const uint32_t* __restrict__ qlist, uint32_t qcap,
                                                    unsigned long long* __restrict__ shadow_px, unsigned long long* __restrict__ counters) {
-    shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR, PF>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
+    shadow_pk_body<COUNT, FILTER, WINDOWS, ENTRY_MAJOR, PF, HEAVY>(s, p, hit_id, t_in, qcount, qlist, qcap, shadow_px, counters);
 }
 // the frames of a batch (srt_render_device_batch): blockIdx.y = frame, gridDim.x waves-of-four pull the units of THAT frame's list.
 // (Waves going on to the next frame's list when theirs is empty: measured twice, 25-35 % SLOWER -- 8,192 waves arriving at a drained
