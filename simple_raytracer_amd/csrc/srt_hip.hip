@@ -905,6 +905,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
     dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.heavy_steps = 0u;                                   // (set below: frames a batch call holds back, and single frames that have the device to themselves)
+    static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();      // walks of this many node steps make a quadrant a heavy one (0 = off)
     static const uint32_t pk_units_default = [] { const char* e = std::getenv("SRT_PK_UNITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
     static const uint32_t pk_take_default = [] { const char* e = std::getenv("SRT_PK_TAKE"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 4u; }();
     const bool in_flight = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) != 0;
@@ -994,7 +995,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         // handle's previous frame are dealt early (srt_kernels.h) -- nothing else fills the slots the launch's tail frees.  Same box:
         // K3 with 16 samples on one stream 4.04 -> 3.70 ms per 8 frames, K4 11.89 -> 11.72; with frames on four streams the lists LOSE
         // (K4 9.41 -> 9.64, the reference's main() scene 6.55 -> 6.91), so the hint turns them off.
-        if (pk_shadow && variant == 0 && (p->flags >> 8 & 0xffu) == 0 && !count && !in_flight && !bc) fp.heavy_steps = 64u;
+        if (pk_shadow && variant == 0 && (p->flags >> 8 & 0xffu) == 0 && !count && !in_flight && !bc) fp.heavy_steps = heavy_default;
         uint32_t* const ql = pk_shadow ? s->ws_qlist : nullptr;      // the closest-hit kernel fills the quadrant list only for a consumer
         uint32_t* const ql_cnt = pk_shadow ? s->d_qcount : nullptr;
         const uint32_t L_CHUNK = p->n_lights / 4 > 4 ? (p->n_lights + 3) / 4 : 4;
@@ -1048,7 +1049,6 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
                 // 2.24 -> 1.73 ms).  Frames launched one by one on several streams pipeline -- the next frame's closest-hit launch fills the
                 // slots a tail frees -- and lose that when the launch ends abruptly (K4 on four streams 10.1 -> 10.5-11.1 ms per 8 frames,
                 // K3 with 16 samples 3.38 -> 3.6-4.0; one stream: no difference): k_shadow_pk is built without the heavy lists.
-                static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
                 it.p.heavy_steps = heavy_default;
                 it.p.pk_take = pk_take_default ? pk_take_default : 1u;      // unit numbers four at a time: fewer same-address atomics (srt_packet.h)
                 it.p.pk_units = 0u;                   // the frames of a batch share the machine: every frame keeps its part of the grid (K3 with 16 samples, an eighth: 0.45 ms per step against 0.68 with surplus waves leaving)

@@ -48,6 +48,14 @@ def main():
                 one.close()
         for h in handles:
             h.close()
+        # a frame alone on the device (no in-flight hint): the same lists from the handle's second render on; with the hint: plain order
+        lone = lib.DeviceScene(g.flat)
+        p16 = abi.make_params(W, H, abi.light_staircase(g.light, 20))
+        want = lib.DeviceScene(g.flat).render(p16)
+        for rep in range(3):
+            got = lone.render(p16 if rep < 2 else abi.make_params(W, H, abi.light_staircase(g.light, 20), flags=abi.SRT_FLAG_FRAMES_IN_FLIGHT))
+            assert np.array_equal(got["hit_id"], want["hit_id"]) and np.array_equal(bits(got["rgb_linear"]), bits(want["rgb_linear"])) and np.array_equal(got["rgb8"], want["rgb8"]), (name, rep)
+        lone.close()
     for ptr in pinned:
         L_.srt_host_free(ptr)
     print("heavy list case: ok")
