@@ -1080,8 +1080,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (pk_shadow) {
             // a fixed number of waves pull units (the shadow rays of 64 / n_lights pixels) from the quadrant list: no grid over the image
             const uint64_t max_units = (uint64_t)n_tiles * 4u * 2u * ((p->n_lights + 7) / 8);
-            static const uint32_t per_cu = [] { const char* e = std::getenv("SRT_PK_WGS_PER_CU"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 8u; }();
-            const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * per_cu ? max_units / 4 + 1 : (uint64_t)s->n_cu * per_cu);
+            const uint32_t wgs = (uint32_t)(max_units / 4 + 1 < (uint64_t)s->n_cu * 8 ? max_units / 4 + 1 : (uint64_t)s->n_cu * 8);      // (8 per CU: every wave slot; fewer was measured)
             if (count)                                hipLaunchKernelGGL((k_shadow_pk<true, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             else if ((p->flags >> 8 & 0xffu) == 29)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, true>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // units in entry order (A/B)
             else if ((p->flags >> 8 & 0xffu) == 55)   hipLaunchKernelGGL((k_shadow_pk<false, true, false, false, 1>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);    // record of i + 1 requested ahead (A/B)
