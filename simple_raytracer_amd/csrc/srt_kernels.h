@@ -328,9 +328,13 @@ constexpr int QL_STRIDE = 16;            // counters 64 B apart
 // K4 frame, 45 % on an eighth of it).  A quadrant's walks are as long in the next frame as in this one (an orbit moves the picture by
 // a few pixels, a benchmark not at all), so the shadow kernel leaves the step count of a quadrant's longest walk in a cost map
 // (one word per quadrant, behind the list: qlist + 2 * QL_SHARDS * qcap words), and the NEXT frame's append reads it (and clears it):
-// quadrants at or above heavy_steps grow from the END of their shard's array (own counters, [2 * QL_SHARDS, 3 * QL_SHARDS)), and the
+// quadrants at or above heavy_steps grow from the END of their shard's array (own counters, [QL_SHARDS, 2 * QL_SHARDS)), and the
 // shadow kernel deals all units of the heavy entries before any other.  Order only: every unit still owns its bytes of the result.
-constexpr int QL_COUNTERS = 3 * QL_SHARDS;      // list lengths | units handed out | heavy-list lengths
+constexpr int QL_FETCH = 64;                     // counters the shadow kernel's waves take their unit numbers from: unit u belongs to counter u % 64.
+                                                 // 256 of them (32 waves per counter instead of 128) were measured at the end of round 3 and are much WORSE
+                                                 // (K4 9.37 -> 10.2 ms per 8 frames, K3 with 64 samples 7.37 -> 10.3; one number per atomic 14.3 / 14.8): the
+                                                 // cost of these atomics is not the waves per address -- fewer atomics (pk_take) is what helps
+constexpr int QL_COUNTERS = 2 * QL_SHARDS + QL_FETCH;      // list lengths | heavy-list lengths | units handed out
 __device__ __forceinline__ uint32_t* quadrant_cost_map(uint32_t* qlist, uint32_t qcap) { return qlist + 2u * (size_t)QL_SHARDS * qcap; }
 __device__ __forceinline__ void quadrant_list_append(uint32_t* __restrict__ qcount, uint32_t* __restrict__ qlist, uint32_t qcap,
                                                      uint32_t tile_index, uint32_t quadrant, uint32_t hit_mask, uint32_t heavy_steps) {
@@ -343,7 +347,7 @@ __device__ __forceinline__ void quadrant_list_append(uint32_t* __restrict__ qcou
         if (c) *cost = 0u;
     }
     if (heavy) {
-        const uint32_t slot = atomicAdd(qcount + (2 * QL_SHARDS + shard) * QL_STRIDE, 1u);
+        const uint32_t slot = atomicAdd(qcount + (QL_SHARDS + shard) * QL_STRIDE, 1u);
         if (slot < qcap) reinterpret_cast<uint2*>(qlist)[(size_t)shard * qcap + (qcap - 1u - slot)] = make_uint2(key, hit_mask);
     } else {
         const uint32_t slot = atomicAdd(qcount + shard * QL_STRIDE, 1u);
@@ -1545,7 +1549,7 @@ __device__ __forceinline__ void trace_nq_body(const DevScene& s, const DevParams
     if (SHADE) {
         if (threadIdx.x == 0) fin_count = 0u;              // (the barrier in finish_background_tile orders this before the first bump)
         if (counters_next) zero_next_counters(counters_next);
-        if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < QL_COUNTERS) qcount[threadIdx.x * QL_STRIDE] = 0u;
+        if (qcount && blockIdx.x == 0 && blockIdx.y == 0) for (uint32_t i = threadIdx.x; i < (uint32_t)QL_COUNTERS; i += 256u) qcount[i * QL_STRIDE] = 0u;
     }
     __shared__ uint32_t nq_all[4][NQCAP];
     __shared__ uint32_t tq_all[4][LQ_WORDS];
@@ -1687,7 +1691,7 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
                                                 unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
     if (counters_next) zero_next_counters(counters_next);
     // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
-    if (qcount && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < QL_COUNTERS) qcount[threadIdx.x * QL_STRIDE] = 0u;      // list lengths + units handed out
+    if (qcount && blockIdx.x == 0 && blockIdx.y == 0) for (uint32_t i = threadIdx.x; i < (uint32_t)QL_COUNTERS; i += 256u) qcount[i * QL_STRIDE] = 0u;      // list lengths + units handed out
 #ifdef SRT_DIAG
     rgb_linear = nullptr;       // holds the trace kernel's stamps in the diagnostic build
 #endif

@@ -398,7 +398,7 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const uint32_t upe = 2u * n_lc8;                                      // units per entry: two groups of 8 hit ranks x the chunks
     const uint32_t pr = lane >> 3, lg = lane & 7u;                        // this lane's pixel slot and light sample within a walk
     // prefix sums over the shard list lengths (HEAVY: heavy lists and the others): lane k holds shard k
-    uint32_t cnt = qcount[lane * QL_STRIDE], cnt_h = HEAVY ? qcount[(2 * QL_SHARDS + lane) * QL_STRIDE] : 0u;
+    uint32_t cnt = qcount[lane * QL_STRIDE], cnt_h = HEAVY ? qcount[(QL_SHARDS + lane) * QL_STRIDE] : 0u;
     cnt = cnt < qcap ? cnt : qcap; cnt_h = cnt_h < qcap ? cnt_h : qcap;
     uint32_t incl = cnt, incl_h = cnt_h;
 #pragma unroll
@@ -410,9 +410,9 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     const uint32_t n_rest = (uint32_t)__shfl((int)incl, 63, 64), n_heavy = HEAVY ? (uint32_t)__shfl((int)incl_h, 63, 64) : 0u;
     const uint32_t n_units = (n_rest + n_heavy) * upe, units_h = n_heavy * upe;
     uint32_t* const cost_map = quadrant_cost_map(const_cast<uint32_t*>(qlist), qcap);
-    // (odd: unit u is fetched through shard u % 64, and an even spacing would put every heavy unit into a few of the 64 shards)
+    // (odd: unit u is fetched through counter u % 64, and an even spacing would put every heavy unit into a few of the counters)
     const uint32_t every = HEAVY && units_h && n_units / (2u * units_h) > 1u ? (n_units / (2u * units_h)) | 1u : 1u;
-    uint32_t* const fetch = qcount + QL_SHARDS * QL_STRIDE;
+    uint32_t* const fetch = qcount + 2 * QL_SHARDS * QL_STRIDE;
     unsigned long long n_node = 0, n_tri = 0;
     unsigned long long diag[5] = { 0, 0, 0, 0, 0 };          // counting build only: steps, node-window loads, triangle iterations, triangle-window loads, walks
     // The grid is sized for the worst case (every tile full of hits); a frame with few units keeps only as many waves as have ~p.pk_units
@@ -420,10 +420,10 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     // 1080p frame with 16 samples are 27 units a wave, most of whose life is start-up and contention on the 64 fetch counters -- K3 with
     // 16 samples 3.40 -> 2.9 ms per 8 frames with the grid cut by hand, K4 (61 units a wave) best with the full grid.
     if (!COUNT && p.pk_units) {
-        const uint32_t keep = n_units / p.pk_units > (uint32_t)QL_SHARDS ? n_units / p.pk_units : (uint32_t)QL_SHARDS;
+        const uint32_t keep = n_units / p.pk_units > (uint32_t)QL_FETCH ? n_units / p.pk_units : (uint32_t)QL_FETCH;
         if (blockIdx.x * 4u + wave >= keep) return;
     }
-    uint32_t home = (blockIdx.x * 4u + wave) & (QL_SHARDS - 1);
+    uint32_t home = (blockIdx.x * 4u + wave) & (QL_FETCH - 1);
     uint32_t k_next = 0;
     // counting build: when this wave started, and what its longest walk was (10 ns ticks of the constant clock)
     constexpr bool TIMING = COUNT || PF < 0;          // PF < 0: the plain walk of the shipped build with the wave clocks of the counting build
@@ -441,15 +441,21 @@ __device__ __forceinline__ void shadow_pk_body(const DevScene& s, const DevParam
     for (;;) {
         const bool fresh = kc == ke;
         if (fresh) { kc = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next); ke = kc + take; }
-        const uint32_t u = kc * QL_SHARDS + home;
+        const uint32_t u = kc * QL_FETCH + home;
         if (u >= n_units) {
             kc = ke = 0;
-            // home shard empty: look (agent-scope loads, the counters only grow) for a shard that still has units, next after home
-            const uint32_t seen = __hip_atomic_load(fetch + lane * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long open = __ballot((unsigned long long)seen * QL_SHARDS + lane < (unsigned long long)n_units);
-            if (!open) break;
-            const unsigned long long rot = home == 63u ? open : ((open >> (home + 1u)) | (open << (63u - home)));      // bit j = shard home + 1 + j
-            home = (home + 1u + (uint32_t)__builtin_ctzll(rot)) & (QL_SHARDS - 1);
+            // home counter used up: look (agent-scope loads, the counters only grow) for one that still has units, next after home
+            // (lane l looks at counter home + 1 + l (+ 64 j, were there more than 64 counters))
+            uint32_t found = 0xffffffffu;
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)QL_FETCH / 64u; j++) {
+                const uint32_t c = (home + 1u + lane + 64u * j) & (QL_FETCH - 1);
+                const uint32_t seen = __hip_atomic_load(fetch + c * QL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long open = __ballot((unsigned long long)seen * QL_FETCH + c < (unsigned long long)n_units);
+                if (open && found == 0xffffffffu) found = (home + 1u + (uint32_t)__builtin_ctzll(open) + 64u * j) & (QL_FETCH - 1);
+            }
+            if (found == 0xffffffffu) break;
+            home = found;
             if (lane == 0) k_next = atomicAdd(fetch + home * QL_STRIDE, take);
             continue;
         }
