@@ -903,7 +903,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     // node-queue kernel (node-major order); 43: the shipped kernels with pushes in lane order.  Shipped (0): node-major order; 32 B records
     // in the fused and the closest-hit kernel, 64 B records in the stand-alone shadow kernel
     const bool all_narrow = variant == 40 || variant == 42, all_wide = variant == 41;
-    dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u);      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
+    dp.exp = ((variant == 40 || variant == 43) ? 1u : 0u) | (variant == 45 ? 2u : 0u) | (variant == 47 ? 4u : 0u) | (variant == 46 ? 8u : 0u) | ((variant == 28 || variant == 2) ? 32u : 0u);      // (28: k_trace_shade_nq has no shading launch behind it, 2: k_closest_hit_q counts itself: the hit statistic is not the shading kernel's)      // (47: diagnostic counters of the wide shadow kernel's steps)      // 45: the tile's root tests by the round-2 loop of dependent loads (A/B)
     dp.heavy_steps = 0u;                                   // (set below: frames a batch call holds back, and single frames that have the device to themselves)
     static const uint32_t heavy_default = [] { const char* e = std::getenv("SRT_HEAVY_STEPS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();      // walks of this many node steps make a quadrant a heavy one (0 = off)
     static const uint32_t pk_units_default = [] { const char* e = std::getenv("SRT_PK_UNITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 64u; }();
@@ -1108,8 +1108,8 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
         if (shaded) { std::snprintf(s->pipeline, sizeof(s->pipeline), "k_trace_shade_nq"); return SRT_OK; }
         DevParams sp = fp;
         sp.shadow_px_major = pk_shadow ? 1u : 0u;
-        if (s->rec->int_shin && variant_of(p) != 44) hipLaunchKernelGGL(k_shade_tile<1>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);
-        else                                         hipLaunchKernelGGL(k_shade_tile<0>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount);      // (44: the general form forced, A/B)
+        if (s->rec->int_shin && variant_of(p) != 44) hipLaunchKernelGGL(k_shade_tile<1>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount, ctr);
+        else                                         hipLaunchKernelGGL(k_shade_tile<0>, grid, block, 0, stream, s->dev, sp, o_hit, o_t, s->ws_shadow, o_lin, o_rgb8, zero_next, s->d_qcount, ctr);      // (44: the general form forced, A/B)
         HIP_TRY(hipGetLastError());
         return SRT_OK;
     };

@@ -786,7 +786,10 @@ __device__ __forceinline__ void closest_hit_phase(const DevScene& s, const DevPa
         is_hit = id >= 0;
         out_id = id; out_t = t;
     }
-    count_hits(counters, is_hit, by * gx + bx);
+    // The hit statistic is taken by the SHADING kernel since the end of round 3 (one atomic per 8x8 tile with hits there instead of one per
+    // quadrant wave here: these fire-and-forget atomics cost the K3 trace launch 4 % -- 0.1157 -> 0.111 ms without them); exp bit 5: the
+    // pipeline has no shading launch behind this phase (k_trace_shade_nq), count here.
+    if (p.exp & 32u) count_hits(counters, is_hit, by * gx + bx);
     if (TWL == 2 && THL == 2 && qlist) {
         const unsigned long long hm = __ballot(is_hit);          // all lanes vote: not inside the lane-0 branch
         if (lane == 0 && hm) quadrant_list_append(qcount, qlist, qcap, by * gx + bx, wave, (uint32_t)hm, p.heavy_steps);
@@ -1688,7 +1691,11 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
                                                 const float* __restrict__ t_in,
                                                 const unsigned long long* __restrict__ shadow_bits,
                                                 float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
+                                                unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount,
+                                                unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t wg_hits, wg_done;
+    if (threadIdx.x == 0) { wg_hits = 0u; wg_done = 0u; }
+    __syncthreads();
     if (counters_next) zero_next_counters(counters_next);
     // the quadrant list of this frame has been consumed by the shadow kernel before this launch: empty it for the next one
     if (qcount && blockIdx.x == 0 && blockIdx.y == 0) for (uint32_t i = threadIdx.x; i < (uint32_t)QL_COUNTERS; i += 256u) qcount[i * QL_STRIDE] = 0u;      // list lengths + units handed out
@@ -1697,11 +1704,24 @@ __device__ __forceinline__ void shade_tile_body(const DevScene& s, const DevPara
 #endif
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t px, r;
-    if (!tile_pixel(p, px, r)) return;
+    const bool live = tile_pixel(p, px, r);
     const size_t pix = (size_t)r * p.W + px;
-    const int32_t id = hit_id[pix];
-    if (id < 0) return;
+    const int32_t id = live ? hit_id[pix] : -1;
     const size_t tile_index = (size_t)(blockIdx.y * 2 + (wave >> 1)) * ((p.W + 7) / 8) + blockIdx.x * 2 + (wave & 1);   // 8x8 tile
+    // The frame's hit statistic, here, where the launch overlaps the next frame's tracing.  The closest-hit phase used to add one global
+    // atomic per 4x4 quadrant with hits (56 k a K3 frame): 4 % of the trace launch; one per 8x8 tile here (14 k) still made this launch
+    // 3.5 us longer.  So the workgroup's four tiles are summed in LDS and the wave that arrives last adds the sum (4 k atomics a frame).
+    if (counters && !(p.exp & 32u)) {
+        const unsigned long long hm = __ballot(id >= 0);
+        if (lane == 0) {
+            if (hm) atomicAdd(&wg_hits, (uint32_t)__popcll(hm));
+            if (atomicAdd(&wg_done, 1u) == 3u) {
+                const uint32_t total = atomicAdd(&wg_hits, 0u);
+                if (total) atomicAdd(counters + CTR_HIT_BASE + 8 * ((blockIdx.y * gridDim.x + blockIdx.x) & (HIT_SHARDS - 1)), (unsigned long long)total);
+            }
+        }
+    }
+    if (id < 0) return;
     const float t = t_in[pix];
     // shadow bits, tile-major (node-queue kernels): per tile and light sample one word, one 16-bit field per 4x4 quadrant (the wave
     // that traced it), bit = y * 4 + x inside the quadrant; pixel-major (packet shadow kernel): per pixel one word per 64 samples
@@ -1726,13 +1746,14 @@ __global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile(DevScene s
                                                     const float* __restrict__ t_in,
                                                     const unsigned long long* __restrict__ shadow_bits,
                                                     float* __restrict__ rgb_linear, uint8_t* __restrict__ rgb8,
-                                                    unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount) {
-    shade_tile_body<INT_SHIN != 0>(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount);
+                                                    unsigned long long* __restrict__ counters_next, uint32_t* __restrict__ qcount,
+                                                    unsigned long long* __restrict__ counters) {
+    shade_tile_body<INT_SHIN != 0>(s, p, hit_id, t_in, shadow_bits, rgb_linear, rgb8, counters_next, qcount, counters);
 }
 template <int INT_SHIN>
 __global__ __launch_bounds__(256, INT_SHIN ? 8 : 1) void k_shade_tile_batch(const FrameTab tab) {      // the shading of the frames k_trace_nq_batch traced
     const FrameItem& it = tab.it[blockIdx.z];
-    shade_tile_body<INT_SHIN != 0>(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount);
+    shade_tile_body<INT_SHIN != 0>(it.s, it.p, it.hit_id, it.t_out, it.shadow_bits, it.rgb_linear, it.rgb8, it.counters_next, it.qcount, it.counters);
 }
 
 // =================================================================================================

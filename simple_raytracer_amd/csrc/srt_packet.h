@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_closest_hit_pk(DevScene s, DevParams p,
     const unsigned long long hm = __ballot(live && id >= 0);
     if (lane == 0 && hm) {
         const uint32_t tile_index = by * tiles_x + bx;
-        atomicAdd(counters + CTR_HIT_BASE + 8 * (tile_index & (HIT_SHARDS - 1)), (unsigned long long)__popcll(hm));
+        if (p.exp & 32u) atomicAdd(counters + CTR_HIT_BASE + 8 * (tile_index & (HIT_SHARDS - 1)), (unsigned long long)__popcll(hm));      // (the shading kernel takes the statistic otherwise)
         if (qlist)
             for (uint32_t q = 0; q < 4; q++) if ((hm >> (16 * q)) & 0xffffull) quadrant_list_append(qcount, qlist, qcap, tile_index, q, (uint32_t)(hm >> (16 * q)) & 0xffffu, p.heavy_steps);
     }
