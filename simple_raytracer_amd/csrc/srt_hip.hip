@@ -910,7 +910,7 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
     static const uint32_t pk_take_default = [] { const char* e = std::getenv("SRT_PK_TAKE"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 4u; }();
     const bool in_flight = (p->flags & SRT_FLAG_FRAMES_IN_FLIGHT) != 0;
     dp.pk_units = in_flight ? pk_units_default : 0u; dp.pk_take = in_flight && pk_take_default ? pk_take_default : 1u;      // (batch frames: set where they are held back)
-    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 59)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
+    if (force_nq || variant == 25 || variant == 29 || variant == 35 || coarse_grid || (variant >= 40 && variant <= 62)) variant = 0;      // (44: the general shading kernel forced)            // 25: variant 0 with the packet shadow kernel reading records through LDS windows (A/B)
     const uint32_t spp = p->spp;
     // workspace of the tile pipeline: per 8x8 tile and light sample one 64-bit word of shadow bits
     // shadow bits: tile-major (one word per tile and light sample, node-queue kernels) or pixel-major (one word per pixel and 64 light
@@ -1092,14 +1092,18 @@ static int render_device_impl(srt_scene* s, const srt_params* p, void* stream_, 
             else                                      hipLaunchKernelGGL((k_shadow_pk<false, true, false>), dim3(wgs), block, 0, stream, s->dev, fp, o_hit, o_t, s->d_qcount, s->ws_qlist, s->qcap, s->ws_shadow, ctr);
             HIP_TRY(hipGetLastError());
         } else if (p->n_lights && !fused) {
-            if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64, 6>), dim3(grid8.x, grid8.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
-                                                      s->dev, fp, o_hit, o_t, s->ws_shadow, ctr, L_CHUNK);
-            else if (count)        hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else if (all_narrow)   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6, false>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);
-            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6>), grid8, block, 0, stream, s->dev, fp, o_hit, o_t, s->ws_shadow, ctr);      // 80 VGPRs: six waves per SIMD (86 without the bound: five)
+            // scenes far bigger than an L2 (fp.xcd_rows): whole tile rows per XCD for the shadow rays too (variant 62 = the plain order, A/B)
+            DevParams sq = fp;
+            if ((p->flags >> 8 & 0xffu) == 62) sq.xcd_rows = 0u;
+            const dim3 gq(grid8.x, sq.xcd_rows ? (grid8.y + 7) / 8 * 8 : grid8.y);
+            if (chunked)           hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 64, 6>), dim3(gq.x, gq.y, (p->n_lights + L_CHUNK - 1) / L_CHUNK), block, 0, stream,
+                                                      s->dev, sq, o_hit, o_t, s->ws_shadow, ctr, L_CHUNK);
+            else if (count)        hipLaunchKernelGGL((k_shadow_nq<true, 512, false>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 3) hipLaunchKernelGGL((k_shadow_nq<false, 160, false>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 6) hipLaunchKernelGGL((k_shadow_nq<false, 160, true>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);
+            else if (variant == 4) hipLaunchKernelGGL((k_shadow_nq<false, 512, false>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);
+            else if (all_narrow)   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6, false>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);
+            else                   hipLaunchKernelGGL((k_shadow_nq<false, 512, true, 16, 6>), gq, block, 0, stream, s->dev, sq, o_hit, o_t, s->ws_shadow, ctr);      // 80 VGPRs: six waves per SIMD (86 without the bound: five)
             HIP_TRY(hipGetLastError());
         }
         if (ev) HIP_TRY(hipEventRecord(ev[2], stream));

@@ -1465,12 +1465,21 @@ __global__ __launch_bounds__(256, MINW) void k_shadow_nq(DevScene s, DevParams p
     __shared__ uint32_t tq_all[4][LQ_WORDS];
     __shared__ ShadowLds<RS> lds_all[4];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t px = blockIdx.x * 8 + (wave & 1) * 4 + (lane & 3), r = blockIdx.y * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
+    // p.xcd_rows (scenes far bigger than an L2; the host pads gridDim.y to a multiple of 8): XCD j walks tile rows j, j + 8, ... left to
+    // right, as the closest-hit kernels of such scenes do -- neighbouring tiles' shadow rays read the same records in the same L2
+    const uint32_t gx = gridDim.x;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_rows) {
+        const uint32_t w = blockIdx.y * gx + blockIdx.x, idx = w >> 3;
+        by = (idx / gx) * 8u + (w & 7u); bx = idx % gx;
+        if (by >= (p.rows + 7u) / 8u) return;
+    }
+    const uint32_t px = bx * 8 + (wave & 1) * 4 + (lane & 3), r = by * 8 + (wave >> 1) * 4 + ((lane >> 2) & 3);
     int32_t id = -1; float t = 0.f;
     V3 d = mk(0.f, 0.f, p.focal);
     if (lane < NQ_P && pixel_live(p, px, r)) { id = hit_id[(size_t)r * p.W + px]; t = t_in[(size_t)r * p.W + px]; d = primary_dir(p, px, image_row(p, r)); }
     const uint32_t l_begin = l_chunk == 0xffffffffu ? 0u : blockIdx.z * l_chunk;
-    shadow_phase<SEQ, NQCAP, FILTER, RS, true, WIDE>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, blockIdx.x, blockIdx.y, gridDim.x, wave,
+    shadow_phase<SEQ, NQCAP, FILTER, RS, true, WIDE>(s, p, nq_all[wave], tq_all[wave], lds_all[wave], id, t, d, shadow_bits, counters, bx, by, gx, wave,
                                          l_begin, l_chunk == 0xffffffffu ? 0xffffffffu : l_begin + l_chunk);
 }
 
