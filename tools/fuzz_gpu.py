@@ -114,6 +114,8 @@ def main():
             stride = int(rng.integers(2, 5)); kw = dict(block_rows=8 * int(rng.integers(1, 3)), block_first=int(rng.integers(0, stride)), block_stride=stride)
         if rng.random() < 0.25:                        # camera mode (extension): the rays are taken into the scene's space by a view matrix
             kw["ray_matrix"] = scenes.orbit_view_matrix(host.Transformation, float(rng.uniform(0, 60)), float(rng.uniform(-40, 40)), float(rng.uniform(-30, 30)), float(rng.uniform(-10, 10)))
+        if rng.random() < 0.3:                         # the in-flight hint (scheduling only): results must not depend on it
+            kw["flags"] = abi.SRT_FLAG_FRAMES_IN_FLIGHT
         p = abi.make_params(W, H, lights, **kw)
         ds = lib.DeviceScene(flat)
         if ds.rows(p) == 0:
@@ -129,7 +131,7 @@ def main():
         # the other forms of the node-queue kernels (64 B records everywhere, 32 B everywhere, the round-2 queue order): the same frame bit for bit
         if "ray_matrix" not in kw:
             for variant in (40, 41, 42):
-                ov = ds.render(abi.make_params(W, H, lights, flags=variant << 8, **kw))
+                ov = ds.render(abi.make_params(W, H, lights, flags=variant << 8, **{k: v for k, v in kw.items() if k != "flags"}))
                 ok = ok and np.array_equal(ov["hit_id"], o["hit_id"]) and np.array_equal(bits(ov["t"]), bits(o["t"])) and np.array_equal(bits(ov["rgb_linear"]), bits(o["rgb_linear"]))
         # the batch call: this frame and a second one with the light moved, on shared records, against the single renders
         twin = ds.share()
