@@ -36,6 +36,20 @@ def test_struct_sizes_match_header(L):
     assert abs(p.gamma - 1.1) < 1e-7 and tuple(p.background)[:3] == (173, 216, 230) and p.spp == 1 and p.flags == 0
 
 
+def test_flag_and_error_constants_match_the_header():
+    """abi.py restates the header's enums by hand: every SRT_FLAG_* / SRT_ERR_* it names must have the header's value."""
+    import re
+    text = open(os.path.join(ROOT, "include", "srt.h")).read()
+    found = {}
+    for name, expr in re.findall(r"\b(SRT_(?:FLAG|ERR)_[A-Z_]+|SRT_OK)\s*=\s*([^,/\n]+)", text):
+        e = expr.strip().replace("u", "")
+        found[name] = eval(e, {"__builtins__": {}})
+    assert {"SRT_FLAG_SMOOTH_NORMALS", "SRT_FLAG_COUNT_WORK", "SRT_FLAG_NO_TIMING", "SRT_FLAG_FRAMES_IN_FLIGHT"} <= set(found)
+    for name, value in found.items():
+        if hasattr(abi, name):
+            assert getattr(abi, name) == value, name
+
+
 def test_light_staircase_and_rows(L, oracle):
     base = np.array([500.0, -300.0, -200.0], np.float32)
     out = np.empty((64, 3), np.float32)
